@@ -1,0 +1,163 @@
+/*
+ * spmv_hip.h -- C-ABI of the MI355X (gfx950) SpMV device layer.
+ *
+ * This is the one NEW seam the build adds to the reference's header surface.
+ * It sits where the reference's CUDA driver talks to the device
+ * (/root/reference/main_cuda.cu): device allocation + upload (:135-145 CSR,
+ * :369-402 HLL), the six kernel launch sites (:166, :238, :317 CSR; :454,
+ * :568, :637 HLL), the per-iteration result copy-back (e.g. :183) and the
+ * frees (:682-685, :731-744).  The shape is the one that driver dictates:
+ * upload once -> run many -> fetch y.
+ *
+ * Conventions (the reference's own, libs/csr_matrix.h / src/csr_matrix.c:74-78):
+ *   - plain C: pointers and sizes only, no C++/torch types;
+ *   - every call returns 0 on success and -1 on failure; nothing in the
+ *     library calls exit(); the message of the last failure is available from
+ *     spmv_hip_last_error();
+ *   - host arrays are borrowed for the duration of the call only; device
+ *     handles are opaque and owned by the library;
+ *   - one host thread, one device per process (multi-GPU = one process per
+ *     GPU; see spmv_hip_comm_* below);
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with -1.
+ *
+ * Reference-side binding: see INTEGRATION.md.
+ */
+#ifndef SPMV_AMD_SPMV_HIP_H
+#define SPMV_AMD_SPMV_HIP_H
+
+#include <stddef.h>
+
+#include "csr_matrix.h"
+#include "hll_matrix.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spmv_csr_dev spmv_csr_dev; /* a CSR matrix (or a row block of one) resident in HBM */
+typedef struct spmv_hll_dev spmv_hll_dev; /* an HLL matrix resident in HBM as one flat slab */
+
+/* CSR kernel selection.  1..3 answer the reference's three CUDA CSR kernels
+ * (cuda_src/csr_matrix_cuda.cu:122-241); 4 has no reference counterpart. */
+enum {
+    SPMV_CSR_AUTO = 0,       /* pick from the matrix' row-length statistics */
+    SPMV_CSR_THREAD_ROW = 1, /* one lane per row            (replaces spmv_csr_naive_kernel) */
+    SPMV_CSR_WAVE_ROW = 2,   /* one 64-lane wavefront per row, 2-wide vector loads
+                                (replaces spmv_csr_warp_kernel) */
+    SPMV_CSR_SUBWAVE = 3,    /* 2..32 lanes per row, picked from mean nnz/row
+                                (replaces spmv_csr_warp_shared_memory_kernel's slot:
+                                the x-cache idea is dropped) */
+    SPMV_CSR_STREAM = 4      /* nnz-balanced row blocks streamed through LDS */
+};
+
+/* HLL kernel selection.  1..3 answer cuda_src/hll_matrix.cu:346-479. */
+enum {
+    SPMV_HLL_AUTO = 0,
+    SPMV_HLL_THREAD_ROW = 1, /* one lane per row over the row-major slab (spmv_hll_naive_kernel) */
+    SPMV_HLL_SUBWAVE = 2,    /* a lane group per row                     (spmv_hll_warp_kernel) */
+    SPMV_HLL_LDS = 3         /* hack slabs staged through LDS            (spmv_hll_warp_shared_kernel_v1) */
+};
+
+typedef struct {
+    int M_local;           /* rows held by this handle                          */
+    int M_total;           /* rows of the whole matrix (length of y)            */
+    int N;                 /* columns (length of x)                             */
+    int row0;              /* first global row of this handle's block           */
+    long long nz;          /* stored entries held by this handle                */
+    int value_bytes;       /* 8 = fp64, 4 = fp32                                */
+    int auto_variant;      /* what SPMV_*_AUTO resolves to                      */
+    int lanes_per_row;     /* SUBWAVE group width chosen at upload              */
+    int stream_blocks;     /* workgroups of the STREAM / LDS kernel             */
+    int long_rows;         /* rows split over several workgroups                */
+    long long slots;       /* HLL only: padded slots S                          */
+    int hacks;             /* HLL only: number of hacks                         */
+    long long algo_bytes;  /* algorithmic HBM bytes of one SpMV  */
+    long long device_bytes;/* HBM held by the handle                            */
+} spmv_dev_info;
+
+/* ---- device ------------------------------------------------------------ */
+int spmv_hip_device_count(void);               /* -1 when HIP itself is unusable */
+int spmv_hip_init(int device);                 /* select device, create the library stream */
+int spmv_hip_shutdown(void);
+int spmv_hip_sync(void);                       /* wait for the library stream */
+void *spmv_hip_stream(void);                   /* the hipStream_t kernels are launched on */
+const char *spmv_hip_last_error(void);
+int spmv_hip_device_name(char *buf, size_t len, int *compute_units, long long *hbm_bytes);
+/* Evict L2 + Infinity Cache by streaming through a scratch buffer of `bytes`
+ * (answers clear_gpu_cache / clear_cache_kernel, cuda_src/utility.cu:140-175;
+ * the reference's 64 MiB is far below MI355X's 256 MiB Infinity Cache). */
+int spmv_hip_flush_cache(size_t bytes);
+
+/* raw device buffers, for callers that keep x / y on the device themselves */
+int spmv_hip_malloc(void **dptr, size_t bytes);
+int spmv_hip_free(void *dptr);
+int spmv_hip_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
+int spmv_hip_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
+int spmv_hip_memset(void *dptr, int byte, size_t bytes);
+
+/* ---- CSR --------------------------------------------------------------- */
+/* Upload rows [row0, row1) of a host CSR matrix (row_ptr has M+1 entries and
+ * is NOT rebased by the caller).  row0 = 0, row1 = M uploads everything.
+ * x and y buffers of full length (N, M) are allocated with the handle. */
+int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
+                        const double *values, int row0, int row1, spmv_csr_dev **out);
+int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx,
+                            const float *values, int row0, int row1, spmv_csr_dev **out);
+/* convenience over the kept struct */
+int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **out);
+void spmv_hip_csr_free(spmv_csr_dev *m);
+int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out);
+
+/* library-owned vectors: host -> x, run, y -> host (y has M_total entries;
+ * this handle writes rows [row0, row0 + M_local) of it) */
+int spmv_hip_csr_set_x(spmv_csr_dev *m, const void *x_host);   /* N values of the handle's dtype */
+int spmv_hip_csr_run(spmv_csr_dev *m, int variant);             /* asynchronous on the library stream */
+int spmv_hip_csr_get_y(spmv_csr_dev *m, void *y_host);          /* syncs, copies M_total values */
+void *spmv_hip_csr_x_ptr(spmv_csr_dev *m);                      /* device pointers of those vectors */
+void *spmv_hip_csr_y_ptr(spmv_csr_dev *m);
+
+/* caller-owned device vectors (d_y points at element 0 of the FULL y) and
+ * caller's stream (NULL = library stream) */
+int spmv_hip_csr_run_on(spmv_csr_dev *m, int variant, const void *d_x, void *d_y, void *stream);
+
+/* The reference's timing protocol (main_cuda.cu:159-200): per iteration zero
+ * y, record an event, launch, record an event; `warmup` untimed iterations
+ * first.  ms_each receives `iters` kernel durations in milliseconds. */
+int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, float *ms_each);
+
+/* ---- HLL --------------------------------------------------------------- */
+/* total_rows = the matrix' M (the last hack may hold fewer than 32 rows). */
+int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out);
+void spmv_hip_hll_free(spmv_hll_dev *m);
+int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out);
+int spmv_hip_hll_set_x(spmv_hll_dev *m, const double *x_host);
+int spmv_hip_hll_run(spmv_hll_dev *m, int variant);
+int spmv_hip_hll_get_y(spmv_hll_dev *m, double *y_host);
+int spmv_hip_hll_run_on(spmv_hll_dev *m, int variant, const void *d_x, void *d_y, void *stream);
+int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, float *ms_each);
+
+/* ---- multi-GPU: one process per GPU, rows split by nnz ------------------ */
+/* Contiguous nnz-balanced row split for `parts` GPUs: the reference's greedy
+ * (prepare_thread_distribution, src/csr_matrix.c:167-266) with fixed-size
+ * output: bounds[0..parts] with bounds[0] = 0, bounds[parts] = M; a part may
+ * be empty (bounds[p] == bounds[p+1]).  Pure host code, no device needed. */
+int spmv_hip_partition_rows(int M, const int *row_ptr, int parts, int *bounds);
+
+/* RCCL communicator over the GPUs of one node.  Rank 0 creates the id
+ * (SPMV_COMM_ID_BYTES opaque bytes) and hands it to the other processes by
+ * any means (the Python host uses torch.distributed's store). */
+#define SPMV_COMM_ID_BYTES 128
+int spmv_hip_comm_get_id(void *id_bytes);
+int spmv_hip_comm_init(const void *id_bytes, int rank, int nranks);
+int spmv_hip_comm_destroy(void);
+/* In-place all-gatherv of y over xGMI: rank r contributes
+ * d_y[bounds[r] .. bounds[r+1]) and receives everybody else's rows, as one
+ * grouped set of ncclBroadcast calls on `stream` (NULL = library stream).
+ * value_bytes is 8 (fp64) or 4 (fp32). */
+int spmv_hip_comm_allgatherv(void *d_y, const int *bounds, int value_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_AMD_SPMV_HIP_H */

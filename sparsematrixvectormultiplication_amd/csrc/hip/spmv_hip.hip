@@ -1,0 +1,796 @@
+// spmv_hip.hip -- the C-ABI of include/spmv_hip.h: device memory management,
+// upload-time preprocessing, kernel launchers, timing and the RCCL exchange.
+//
+// This translation unit stands where the reference's CUDA driver touches the
+// device (/root/reference/main_cuda.cu:135-145, :149-166, :212-238, :285-317,
+// :369-455, :545-568, :613-637, :682-744).  Nothing here computes on the host:
+// if HIP is unusable every entry point returns -1 with a message.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "csr_kernels.hpp"
+#include "hll_kernels.hpp"
+#include "spmv_hip.h"
+
+using namespace spmv;
+
+// ------------------------------------------------------------------ state
+namespace {
+
+thread_local char g_error[512] = "";
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+void *g_flush_buf = nullptr;
+size_t g_flush_bytes = 0;
+ncclComm_t g_comm = nullptr;
+int g_comm_rank = 0, g_comm_size = 1;
+
+int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t err__ = (expr);                                                        \
+        if (err__ != hipSuccess)                                                          \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, \
+                        __LINE__);                                                        \
+    } while (0)
+
+#define NCCL_TRY(expr)                                                                     \
+    do {                                                                                   \
+        ncclResult_t err__ = (expr);                                                       \
+        if (err__ != ncclSuccess)                                                          \
+            return fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(err__), __FILE__, \
+                        __LINE__);                                                         \
+    } while (0)
+
+int need_device() {
+    if (g_device < 0) return fail("spmv_hip_init() has not been called (or failed): no HIP device");
+    return 0;
+}
+
+constexpr int kPad = 64;  // zero entries behind col/val so 2-wide peels stay in bounds
+
+template <typename T>
+int upload_array(T **dptr, const T *host, size_t count, size_t pad) {
+    HIP_TRY(hipMalloc((void **)dptr, (count + pad) * sizeof(T)));
+    if (count) HIP_TRY(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+    if (pad) HIP_TRY(hipMemset(*dptr + count, 0, pad * sizeof(T)));
+    return 0;
+}
+
+int pow2_floor(int v) {
+    int p = 1;
+    while (p * 2 <= v) p *= 2;
+    return p;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- handles
+struct spmv_csr_dev {
+    int value_bytes = 8;
+    int M_local = 0, M_total = 0, N = 0, row0 = 0;
+    long long nz = 0;
+    int *row_ptr = nullptr;  // [M_local + 1], rebased to 0
+    int *col = nullptr;
+    void *val = nullptr;
+    void *x = nullptr;  // [N]
+    void *y = nullptr;  // [M_total]
+    // stream kernel
+    int4 *desc = nullptr;
+    int num_blocks = 0;
+    int4 *long_rows = nullptr;
+    int num_long = 0;
+    void *partial = nullptr;
+    int num_partial = 0;
+    // heuristics
+    int lanes_per_row = 16;
+    int auto_variant = SPMV_CSR_STREAM;
+    int max_row = 0;
+    size_t device_bytes = 0;
+};
+
+struct spmv_hll_dev {
+    int M = 0, N = 0, hacks = 0;
+    long long nz_hint = 0;
+    long long slots = 0;
+    long long *hack_off = nullptr;  // [hacks + 1]
+    int *maxnz = nullptr;           // [hacks]
+    int *JA = nullptr;
+    double *AS = nullptr;
+    int *hblk = nullptr;  // [num_blocks + 1]
+    int num_blocks = 0;
+    double *x = nullptr;
+    double *y = nullptr;
+    int lanes_per_row = 8;
+    int auto_variant = SPMV_HLL_LDS;
+    size_t device_bytes = 0;
+};
+
+// ------------------------------------------------------------------ device
+extern "C" int spmv_hip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return n;
+}
+
+extern "C" int spmv_hip_init(int device) {
+    int n = spmv_hip_device_count();
+    if (n <= 0) return n < 0 ? -1 : fail("no HIP device visible");
+    if (device < 0 || device >= n) return fail("device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    if (g_stream && g_device != device) {
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    return 0;
+}
+
+extern "C" int spmv_hip_shutdown(void) {
+    if (g_comm) {
+        (void)ncclCommDestroy(g_comm);
+        g_comm = nullptr;
+    }
+    if (g_flush_buf) {
+        (void)hipFree(g_flush_buf);
+        g_flush_buf = nullptr;
+        g_flush_bytes = 0;
+    }
+    if (g_stream) {
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    g_device = -1;
+    return 0;
+}
+
+extern "C" int spmv_hip_sync(void) {
+    if (need_device()) return -1;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" void *spmv_hip_stream(void) { return (void *)g_stream; }
+
+extern "C" const char *spmv_hip_last_error(void) { return g_error; }
+
+extern "C" int spmv_hip_device_name(char *buf, size_t len, int *compute_units, long long *hbm_bytes) {
+    if (need_device()) return -1;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    if (buf && len) snprintf(buf, len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (long long)prop.totalGlobalMem;
+    return 0;
+}
+
+extern "C" int spmv_hip_flush_cache(size_t bytes) {
+    if (need_device()) return -1;
+    if (bytes < 16) bytes = 16;
+    if (bytes > g_flush_bytes) {
+        if (g_flush_buf) HIP_TRY(hipFree(g_flush_buf));
+        g_flush_buf = nullptr;
+        g_flush_bytes = 0;
+        HIP_TRY(hipMalloc(&g_flush_buf, bytes));
+        HIP_TRY(hipMemset(g_flush_buf, 0, bytes));
+        g_flush_bytes = bytes;
+    }
+    hipLaunchKernelGGL(flush_kernel, dim3(2048), dim3(kBlock), 0, g_stream, (uint4 *)g_flush_buf,
+                       bytes / 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int spmv_hip_malloc(void **dptr, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+extern "C" int spmv_hip_free(void *dptr) {
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return 0;
+}
+extern "C" int spmv_hip_memcpy_h2d(void *dptr, const void *hptr, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipMemcpy(dptr, hptr, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int spmv_hip_memcpy_d2h(void *hptr, const void *dptr, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(hptr, dptr, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int spmv_hip_memset(void *dptr, int byte, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipMemsetAsync(dptr, byte, bytes, g_stream));
+    return 0;
+}
+
+// ----------------------------------------------------------- CSR: upload
+namespace {
+
+// Cut rows [0, M) (row_ptr rebased to 0) into workgroup-sized pieces for
+// csr_stream: each descriptor is {first row | flag, first entry, partial slot, 0}
+// and a final sentinel {M, nnz, 0, 0} closes the last block.
+void csr_build_blocks(int M, const int *rp, std::vector<int4> &desc, std::vector<int4> &long_rows,
+                      int &num_partial) {
+    desc.clear();
+    long_rows.clear();
+    num_partial = 0;
+    int r = 0;
+    while (r < M) {
+        const int n0 = rp[r];
+        const int len = rp[r + 1] - n0;
+        const int base = n0 & ~1;
+        if (len > kStreamCap - 1) {
+            // a row that cannot be staged: split into pieces, summed by csr_long_finish
+            const int first_slot = num_partial;
+            int pieces = 0;
+            for (int p = n0; p < rp[r + 1]; p += kLongPiece) {
+                desc.push_back(int4{r | kLongFlag, p, num_partial++, 0});
+                ++pieces;
+            }
+            long_rows.push_back(int4{r, first_slot, pieces, 0});
+            ++r;
+            continue;
+        }
+        int r1 = r;
+        while (r1 < M && r1 - r < kStreamRowsCap && rp[r1 + 1] - base <= kStreamCap &&
+               rp[r1 + 1] - rp[r1] <= kStreamCap - 1)
+            ++r1;
+        desc.push_back(int4{r, n0, 0, 0});
+        r = r1;
+    }
+    desc.push_back(int4{M, M > 0 ? rp[M] : 0, 0, 0});
+}
+
+template <typename T>
+int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const T *values, int row0,
+                    int row1, spmv_csr_dev **out) {
+    if (need_device()) return -1;
+    if (!out) return fail("csr_upload: out is NULL");
+    *out = nullptr;
+    if (M < 0 || N < 0 || !row_ptr) return fail("csr_upload: bad arguments");
+    if (row0 < 0 || row1 < row0 || row1 > M) return fail("csr_upload: bad row range [%d, %d) of %d", row0, row1, M);
+    if (M >= kLongFlag) return fail("csr_upload: M = %d exceeds the supported 2^30 - 1 rows", M);
+    const int Ml = row1 - row0;
+    const int e0 = row_ptr[row0], e1 = row_ptr[row1];
+    const long long nz = (long long)e1 - e0;
+    if (nz < 0) return fail("csr_upload: row_ptr is not monotone");
+    if (nz > 0 && (!col_idx || !values)) return fail("csr_upload: col_idx / values are NULL");
+
+    spmv_csr_dev *m = new (std::nothrow) spmv_csr_dev();
+    if (!m) return fail("csr_upload: out of host memory");
+    m->value_bytes = (int)sizeof(T);
+    m->M_local = Ml;
+    m->M_total = M;
+    m->N = N;
+    m->row0 = row0;
+    m->nz = nz;
+
+    std::vector<int> rp((size_t)Ml + 1);
+    int max_row = 0;
+    for (int r = 0; r <= Ml; ++r) rp[r] = row_ptr[row0 + r] - e0;
+    for (int r = 0; r < Ml; ++r) {
+        if (rp[r + 1] < rp[r]) {
+            delete m;
+            return fail("csr_upload: row_ptr decreases at row %d", row0 + r);
+        }
+        max_row = std::max(max_row, rp[r + 1] - rp[r]);
+    }
+    m->max_row = max_row;
+
+    std::vector<int4> desc, long_rows;
+    int num_partial = 0;
+    csr_build_blocks(Ml, rp.data(), desc, long_rows, num_partial);
+    m->num_blocks = (int)desc.size() - 1;
+    m->num_long = (int)long_rows.size();
+    m->num_partial = num_partial;
+
+    int rc = 0;
+    rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), 0);
+    if (!rc) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
+    if (!rc) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
+    if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 0);
+    if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
+    if (!rc && num_partial) {
+        hipError_t e = hipMalloc(&m->partial, (size_t)num_partial * sizeof(T));
+        if (e != hipSuccess) rc = fail("hipMalloc(partial) failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        hipError_t e = hipMalloc(&m->x, std::max<size_t>((size_t)N, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMalloc(&m->y, std::max<size_t>((size_t)M, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMemset(m->x, 0, std::max<size_t>((size_t)N, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)M, 1) * sizeof(T));
+        if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        spmv_hip_csr_free(m);
+        return -1;
+    }
+    m->device_bytes = rp.size() * 4 + ((size_t)nz + kPad) * (4 + sizeof(T)) + desc.size() * 16 +
+                      long_rows.size() * 16 + (size_t)num_partial * sizeof(T) +
+                      ((size_t)N + (size_t)M) * sizeof(T);
+
+    // lanes per row for the SUBWAVE kernel: about half the mean row length,
+    // rounded to a power of two, so that a typical row takes 1-2 passes
+    const double mean = Ml ? (double)nz / Ml : 0.0;
+    int lanes = pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)));
+    m->lanes_per_row = std::min(32, std::max(2, lanes));
+    m->auto_variant = SPMV_CSR_STREAM;
+    *out = m;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
+                                   const double *values, int row0, int row1, spmv_csr_dev **out) {
+    return csr_upload_impl<double>(M, N, row_ptr, col_idx, values, row0, row1, out);
+}
+
+extern "C" int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx,
+                                       const float *values, int row0, int row1, spmv_csr_dev **out) {
+    return csr_upload_impl<float>(M, N, row_ptr, col_idx, values, row0, row1, out);
+}
+
+extern "C" int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **out) {
+    if (!csr) return fail("csr_upload_matrix: csr is NULL");
+    return spmv_hip_csr_upload(csr->M, csr->N, csr->row_ptr, csr->col_idx, csr->values, 0, csr->M, out);
+}
+
+extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
+    if (!m) return;
+    (void)hipFree(m->row_ptr);
+    (void)hipFree(m->col);
+    (void)hipFree(m->val);
+    (void)hipFree(m->desc);
+    (void)hipFree(m->long_rows);
+    (void)hipFree(m->partial);
+    (void)hipFree(m->x);
+    (void)hipFree(m->y);
+    delete m;
+}
+
+extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
+    if (!m || !out) return fail("csr_info: NULL argument");
+    memset(out, 0, sizeof *out);
+    out->M_local = m->M_local;
+    out->M_total = m->M_total;
+    out->N = m->N;
+    out->row0 = m->row0;
+    out->nz = m->nz;
+    out->value_bytes = m->value_bytes;
+    out->auto_variant = m->auto_variant;
+    out->lanes_per_row = m->lanes_per_row;
+    out->stream_blocks = m->num_blocks;
+    out->long_rows = m->num_long;
+    const long long vb = m->value_bytes;
+    // nnz (val + 4) + 4 (M + 1) + val M [y] + val N [x]
+    out->algo_bytes = m->nz * (vb + 4) + 4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
+    out->device_bytes = (long long)m->device_bytes;
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_set_x(spmv_csr_dev *m, const void *x_host) {
+    if (need_device()) return -1;
+    if (!m || !x_host) return fail("csr_set_x: NULL argument");
+    HIP_TRY(hipMemcpyAsync(m->x, x_host, (size_t)m->N * m->value_bytes, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_get_y(spmv_csr_dev *m, void *y_host) {
+    if (need_device()) return -1;
+    if (!m || !y_host) return fail("csr_get_y: NULL argument");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(y_host, m->y, (size_t)m->M_total * m->value_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" void *spmv_hip_csr_x_ptr(spmv_csr_dev *m) { return m ? m->x : nullptr; }
+extern "C" void *spmv_hip_csr_y_ptr(spmv_csr_dev *m) { return m ? m->y : nullptr; }
+
+// ----------------------------------------------------------- CSR: launch
+namespace {
+
+template <typename T, int L>
+void launch_vector(const spmv_csr_dev *m, const T *x, T *y, hipStream_t s) {
+    constexpr int rows = kBlock / L;
+    const int grid = (m->M_local + rows - 1) / rows;
+    hipLaunchKernelGGL((csr_vector<T, L, 1, false>), dim3(grid), dim3(kBlock), 0, s, m->M_local,
+                       m->row_ptr, m->col, (const T *)m->val, x, y);
+}
+
+template <typename T>
+int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStream_t s) {
+    if (m->M_local == 0) return 0;
+    T *y = y_full + m->row0;
+    if (variant == SPMV_CSR_AUTO) variant = m->auto_variant;
+    switch (variant) {
+        case SPMV_CSR_THREAD_ROW: {
+            const int grid = (m->M_local + kBlock - 1) / kBlock;
+            hipLaunchKernelGGL((csr_thread_row<T>), dim3(grid), dim3(kBlock), 0, s, m->M_local,
+                               m->row_ptr, m->col, (const T *)m->val, x, y);
+            break;
+        }
+        case SPMV_CSR_WAVE_ROW: {
+            constexpr int rows = kBlock / 64;
+            const int grid = (m->M_local + rows - 1) / rows;
+            hipLaunchKernelGGL((csr_vector<T, 64, 2, true>), dim3(grid), dim3(kBlock), 0, s,
+                               m->M_local, m->row_ptr, m->col, (const T *)m->val, x, y);
+            break;
+        }
+        case SPMV_CSR_SUBWAVE:
+            switch (m->lanes_per_row) {
+                case 2: launch_vector<T, 2>(m, x, y, s); break;
+                case 4: launch_vector<T, 4>(m, x, y, s); break;
+                case 8: launch_vector<T, 8>(m, x, y, s); break;
+                case 16: launch_vector<T, 16>(m, x, y, s); break;
+                default: launch_vector<T, 32>(m, x, y, s); break;
+            }
+            break;
+        case SPMV_CSR_STREAM: {
+            const int per_xcd = (m->num_blocks + 7) / 8;
+            hipLaunchKernelGGL((csr_stream<T, true, true>), dim3(per_xcd * 8), dim3(kBlock), 0, s,
+                               m->num_blocks, per_xcd, m->desc, m->row_ptr, m->col,
+                               (const T *)m->val, x, y, (T *)m->partial);
+            if (m->num_long)
+                hipLaunchKernelGGL((csr_long_finish<T>), dim3(m->num_long), dim3(64), 0, s,
+                                   m->num_long, m->long_rows, (const T *)m->partial, y);
+            break;
+        }
+        default:
+            return fail("unknown CSR variant %d", variant);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s) {
+    if (m->value_bytes == 8) return csr_launch<double>(m, variant, (const double *)x, (double *)y, s);
+    return csr_launch<float>(m, variant, (const float *)x, (float *)y, s);
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_run(spmv_csr_dev *m, int variant) {
+    if (need_device()) return -1;
+    if (!m) return fail("csr_run: NULL handle");
+    return csr_launch_any(m, variant, m->x, m->y, g_stream);
+}
+
+extern "C" int spmv_hip_csr_run_on(spmv_csr_dev *m, int variant, const void *d_x, void *d_y, void *stream) {
+    if (need_device()) return -1;
+    if (!m || !d_x || !d_y) return fail("csr_run_on: NULL argument");
+    return csr_launch_any(m, variant, d_x, d_y, stream ? (hipStream_t)stream : g_stream);
+}
+
+namespace {
+
+// events around each launch on the stream the kernel runs on
+template <typename Launch, typename Zero>
+int time_loop(int warmup, int iters, float *ms_each, Launch launch, Zero zero_y) {
+    if (iters <= 0 || !ms_each) return fail("time: iters must be > 0 and ms_each non-NULL");
+    std::vector<hipEvent_t> ev((size_t)iters * 2);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = 0;
+    for (int i = 0; i < warmup && !rc; ++i) {
+        rc = zero_y();
+        if (!rc) rc = launch();
+    }
+    for (int i = 0; i < iters && !rc; ++i) {
+        rc = zero_y();
+        if (rc) break;
+        HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
+        rc = launch();
+        HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
+    }
+    if (!rc) {
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        for (int i = 0; i < iters; ++i) HIP_TRY(hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, float *ms_each) {
+    if (need_device()) return -1;
+    if (!m) return fail("csr_time: NULL handle");
+    return time_loop(
+        warmup, iters, ms_each, [&] { return csr_launch_any(m, variant, m->x, m->y, g_stream); },
+        [&]() -> int {
+            HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M_total * m->value_bytes, g_stream));
+            return 0;
+        });
+}
+
+// ----------------------------------------------------------------- HLL
+namespace {
+
+// group consecutive hacks into workgroups of at most kHllCap slots
+void hll_build_blocks(int hacks, const long long *off, std::vector<int> &hblk) {
+    hblk.clear();
+    int h = 0;
+    while (h < hacks) {
+        hblk.push_back(h);
+        int h1 = h + 1;
+        while (h1 < hacks && off[h1 + 1] - off[h] <= kHllCap && h1 - h < 8) ++h1;
+        h = h1;
+    }
+    hblk.push_back(hacks);
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
+    if (need_device()) return -1;
+    if (!hll || !out) return fail("hll_upload: NULL argument");
+    *out = nullptr;
+    const int H = hll->num_blocks;
+    if (H != (total_rows + kHack - 1) / kHack)
+        return fail("hll_upload: %d hacks do not match %d rows", H, total_rows);
+
+    std::vector<long long> off((size_t)H + 1, 0);
+    std::vector<int> mz((size_t)H, 0);
+    long long true_slots = 0;
+    for (int h = 0; h < H; ++h) {
+        const ELLPACKBlock *b = &hll->blocks[h];
+        const int expect = (h == H - 1) ? total_rows - h * kHack : kHack;
+        if (b->M != expect) return fail("hll_upload: hack %d holds %d rows, expected %d", h, b->M, expect);
+        if (b->MAXNZ < 0 || (b->MAXNZ > 0 && (!b->JA || !b->AS)))
+            return fail("hll_upload: hack %d is malformed", h);
+        mz[h] = b->MAXNZ;
+        const long long s = (long long)b->M * b->MAXNZ;
+        true_slots += s;
+        off[h + 1] = off[h] + ((s + 1) & ~1LL);  // next hack starts on an even slot
+    }
+    const long long S = off[H];
+    if (S > (1LL << 40)) return fail("hll_upload: %lld padded slots is unreasonable", S);
+
+    // pack every hack into one flat pair of host arrays, then two copies
+    std::vector<int> ja((size_t)S + kPad, 0);
+    std::vector<double> as((size_t)S + kPad, 0.0);
+    for (int h = 0; h < H; ++h) {
+        const ELLPACKBlock *b = &hll->blocks[h];
+        const size_t s = (size_t)b->M * b->MAXNZ;
+        if (!s) continue;
+        memcpy(&ja[(size_t)off[h]], b->JA, s * sizeof(int));
+        memcpy(&as[(size_t)off[h]], b->AS, s * sizeof(double));
+    }
+    std::vector<int> hblk;
+    hll_build_blocks(H, off.data(), hblk);
+
+    spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
+    if (!m) return fail("hll_upload: out of host memory");
+    m->M = total_rows;
+    m->N = N;
+    m->hacks = H;
+    m->slots = true_slots;
+    m->num_blocks = (int)hblk.size() - 1;
+    int rc = 0;
+    rc |= upload_array(&m->hack_off, off.data(), off.size(), 0);
+    if (!rc) rc |= upload_array(&m->maxnz, mz.data(), mz.size(), 1);
+    if (!rc) rc |= upload_array(&m->JA, ja.data(), ja.size(), 0);
+    if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
+    if (!rc) rc |= upload_array(&m->hblk, hblk.data(), hblk.size(), 0);
+    if (!rc) {
+        hipError_t e = hipMalloc((void **)&m->x, std::max<size_t>((size_t)N, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(m->x, 0, std::max<size_t>((size_t)N, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
+        if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        spmv_hip_hll_free(m);
+        return -1;
+    }
+    m->device_bytes = off.size() * 8 + mz.size() * 4 + ja.size() * 4 + as.size() * 8 + hblk.size() * 4 +
+                      ((size_t)N + (size_t)total_rows) * 8;
+    const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
+    m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
+    *out = m;
+    return 0;
+}
+
+extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
+    if (!m) return;
+    (void)hipFree(m->hack_off);
+    (void)hipFree(m->maxnz);
+    (void)hipFree(m->JA);
+    (void)hipFree(m->AS);
+    (void)hipFree(m->hblk);
+    (void)hipFree(m->x);
+    (void)hipFree(m->y);
+    delete m;
+}
+
+extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
+    if (!m || !out) return fail("hll_info: NULL argument");
+    memset(out, 0, sizeof *out);
+    out->M_local = out->M_total = m->M;
+    out->N = m->N;
+    out->value_bytes = 8;
+    out->auto_variant = m->auto_variant;
+    out->lanes_per_row = m->lanes_per_row;
+    out->stream_blocks = m->num_blocks;
+    out->slots = m->slots;
+    out->hacks = m->hacks;
+    // S (val + 4) + 12 H + val (M + N)
+    out->algo_bytes = m->slots * 12 + 12LL * m->hacks + 8LL * ((long long)m->M + m->N);
+    out->device_bytes = (long long)m->device_bytes;
+    return 0;
+}
+
+extern "C" int spmv_hip_hll_set_x(spmv_hll_dev *m, const double *x_host) {
+    if (need_device()) return -1;
+    if (!m || !x_host) return fail("hll_set_x: NULL argument");
+    HIP_TRY(hipMemcpyAsync(m->x, x_host, (size_t)m->N * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int spmv_hip_hll_get_y(spmv_hll_dev *m, double *y_host) {
+    if (need_device()) return -1;
+    if (!m || !y_host) return fail("hll_get_y: NULL argument");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(y_host, m->y, (size_t)m->M * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+namespace {
+
+template <int L>
+void launch_hll_vector(const spmv_hll_dev *m, const double *x, double *y, hipStream_t s) {
+    constexpr int rows = kBlock / L;
+    hipLaunchKernelGGL((hll_vector<double, L>), dim3((m->M + rows - 1) / rows), dim3(kBlock), 0, s,
+                       m->M, m->hack_off, m->maxnz, m->JA, m->AS, x, y);
+}
+
+int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y, hipStream_t s) {
+    if (m->M == 0) return 0;
+    if (variant == SPMV_HLL_AUTO) variant = m->auto_variant;
+    switch (variant) {
+        case SPMV_HLL_THREAD_ROW:
+            hipLaunchKernelGGL((hll_thread_row<double>), dim3((m->M + kBlock - 1) / kBlock),
+                               dim3(kBlock), 0, s, m->M, m->hack_off, m->maxnz, m->JA, m->AS, x, y);
+            break;
+        case SPMV_HLL_SUBWAVE:
+            switch (m->lanes_per_row) {
+                case 2: launch_hll_vector<2>(m, x, y, s); break;
+                case 4: launch_hll_vector<4>(m, x, y, s); break;
+                case 8: launch_hll_vector<8>(m, x, y, s); break;
+                case 16: launch_hll_vector<16>(m, x, y, s); break;
+                default: launch_hll_vector<32>(m, x, y, s); break;
+            }
+            break;
+        case SPMV_HLL_LDS:
+            hipLaunchKernelGGL((hll_lds<double, true>), dim3(m->num_blocks), dim3(kBlock), 0, s, m->M,
+                               m->hblk, m->hack_off, m->maxnz, m->JA, m->AS, x, y);
+            break;
+        default:
+            return fail("unknown HLL variant %d", variant);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_hll_run(spmv_hll_dev *m, int variant) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_run: NULL handle");
+    return hll_launch(m, variant, m->x, m->y, g_stream);
+}
+
+extern "C" int spmv_hip_hll_run_on(spmv_hll_dev *m, int variant, const void *d_x, void *d_y, void *stream) {
+    if (need_device()) return -1;
+    if (!m || !d_x || !d_y) return fail("hll_run_on: NULL argument");
+    return hll_launch(m, variant, (const double *)d_x, (double *)d_y, stream ? (hipStream_t)stream : g_stream);
+}
+
+extern "C" int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, float *ms_each) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_time: NULL handle");
+    return time_loop(
+        warmup, iters, ms_each, [&] { return hll_launch(m, variant, m->x, m->y, g_stream); },
+        [&]() -> int {
+            HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M * 8, g_stream));
+            return 0;
+        });
+}
+
+// ------------------------------------------------------------- multi-GPU
+extern "C" int spmv_hip_partition_rows(int M, const int *row_ptr, int parts, int *bounds) {
+    if (M < 0 || parts <= 0 || !bounds || (M > 0 && !row_ptr)) return fail("partition_rows: bad arguments");
+    for (int p = 0; p <= parts; ++p) bounds[p] = M;
+    bounds[0] = 0;
+    if (M == 0) return 0;
+    int *start = nullptr, *end = nullptr;
+    const long long total = (long long)row_ptr[M] - row_ptr[0];
+    const int got = prepare_thread_distribution(M, row_ptr, parts, total, &start, &end);
+    // chunks are contiguous and ordered; rows of trailing empty chunks (if any)
+    // and rows skipped by dropped zero-nnz chunks go to their left neighbour
+    for (int p = 0; p < got; ++p) bounds[p + 1] = (p == got - 1) ? M : start[p + 1];
+    for (int p = got + 1; p <= parts; ++p) bounds[p] = M;
+    if (got == 0) bounds[1] = M;  // matrix without nonzeros: everything to part 0
+    free(start);
+    free(end);
+    return 0;
+}
+
+extern "C" int spmv_hip_comm_get_id(void *id_bytes) {
+    if (!id_bytes) return fail("comm_get_id: NULL buffer");
+    static_assert(sizeof(ncclUniqueId) <= SPMV_COMM_ID_BYTES, "id buffer too small");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memset(id_bytes, 0, SPMV_COMM_ID_BYTES);
+    memcpy(id_bytes, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int spmv_hip_comm_init(const void *id_bytes, int rank, int nranks) {
+    if (need_device()) return -1;
+    if (!id_bytes || rank < 0 || rank >= nranks) return fail("comm_init: bad arguments");
+    if (g_comm) return fail("comm_init: communicator already exists");
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    NCCL_TRY(ncclCommInitRank(&g_comm, nranks, id, rank));
+    g_comm_rank = rank;
+    g_comm_size = nranks;
+    return 0;
+}
+
+extern "C" int spmv_hip_comm_destroy(void) {
+    if (g_comm) {
+        NCCL_TRY(ncclCommDestroy(g_comm));
+        g_comm = nullptr;
+    }
+    g_comm_rank = 0;
+    g_comm_size = 1;
+    return 0;
+}
+
+extern "C" int spmv_hip_comm_allgatherv(void *d_y, const int *bounds, int value_bytes, void *stream) {
+    if (need_device()) return -1;
+    if (!g_comm) return fail("comm_allgatherv: no communicator (call spmv_hip_comm_init)");
+    if (!d_y || !bounds) return fail("comm_allgatherv: NULL argument");
+    if (value_bytes != 8 && value_bytes != 4) return fail("comm_allgatherv: value_bytes must be 4 or 8");
+    hipStream_t s = stream ? (hipStream_t)stream : g_stream;
+    const ncclDataType_t dt = value_bytes == 8 ? ncclDouble : ncclFloat;
+    // RCCL has no all-gather-v: one broadcast per owner, fused into one group
+    // so the 7 peer copies of every slice go out over distinct xGMI links at once
+    NCCL_TRY(ncclGroupStart());
+    for (int r = 0; r < g_comm_size; ++r) {
+        const size_t count = (size_t)(bounds[r + 1] - bounds[r]);
+        if (!count) continue;
+        char *slice = (char *)d_y + (size_t)bounds[r] * value_bytes;
+        NCCL_TRY(ncclBroadcast(slice, slice, count, dt, r, g_comm, s));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+}

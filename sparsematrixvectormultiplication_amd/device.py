@@ -1,0 +1,190 @@
+"""GPU side of the path: thin objects over the C-ABI of include/spmv_hip.h.
+
+Shape dictated by the reference's CUDA driver (main_cuda.cu): upload once
+(:135-145, :369-402) -> run many (:166, :238, :317, :454, :568, :637) ->
+fetch y (:183).  No CPU fallback anywhere: a failed C call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from .host import CsrHost, HllHost
+
+CSR_AUTO, CSR_THREAD_ROW, CSR_WAVE_ROW, CSR_SUBWAVE, CSR_STREAM = 0, 1, 2, 3, 4
+HLL_AUTO, HLL_THREAD_ROW, HLL_SUBWAVE, HLL_LDS = 0, 1, 2, 3
+CSR_VARIANTS = {"thread_row": CSR_THREAD_ROW, "wave_row": CSR_WAVE_ROW, "subwave": CSR_SUBWAVE,
+                "stream": CSR_STREAM}
+HLL_VARIANTS = {"thread_row": HLL_THREAD_ROW, "subwave": HLL_SUBWAVE, "lds": HLL_LDS}
+
+
+class SpmvHipError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = nat.lib().spmv_hip_last_error()
+        raise SpmvHipError(f"{what}: {msg.decode(errors='replace') if msg else 'failed (-1)'}")
+
+
+def device_count() -> int:
+    return nat.lib().spmv_hip_device_count()
+
+
+def hip_init(device: int = 0) -> None:
+    _check(nat.lib().spmv_hip_init(int(device)), "spmv_hip_init")
+
+
+def hip_sync() -> None:
+    _check(nat.lib().spmv_hip_sync(), "spmv_hip_sync")
+
+
+def hip_stream() -> int:
+    return nat.lib().spmv_hip_stream() or 0
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    cus, mem = C.c_int(), C.c_longlong()
+    _check(nat.lib().spmv_hip_device_name(buf, 256, C.byref(cus), C.byref(mem)), "device_name")
+    return buf.value.decode(), cus.value, mem.value
+
+
+def flush_cache(nbytes: int = 1 << 30) -> None:
+    """Refill L2 + the 256 MiB Infinity Cache with scratch data."""
+    _check(nat.lib().spmv_hip_flush_cache(int(nbytes)), "spmv_hip_flush_cache")
+
+
+class _Handle:
+    _free = None
+
+    def __init__(self):
+        self.h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            getattr(nat.lib(), self._free)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class CsrDevice(_Handle):
+    """A CSR matrix, or rows [row0, row1) of one, resident in HBM."""
+
+    _free = "spmv_hip_csr_free"
+
+    def __init__(self, M, N, row_ptr, col_idx, values, row0=0, row1=None):
+        super().__init__()
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        if values.dtype == np.float32:
+            values = np.ascontiguousarray(values)
+            fn, vp, self.dtype = nat.lib().spmv_hip_csr_upload_f32, nat.c_float_p, np.float32
+        else:
+            values = np.ascontiguousarray(values, dtype=np.float64)
+            fn, vp, self.dtype = nat.lib().spmv_hip_csr_upload, nat.c_double_p, np.float64
+        if len(row_ptr) != M + 1:
+            raise ValueError("row_ptr must have M + 1 entries")
+        row1 = M if row1 is None else row1
+        _check(fn(int(M), int(N), row_ptr.ctypes.data_as(nat.c_int_p),
+                  col_idx.ctypes.data_as(nat.c_int_p), values.ctypes.data_as(vp), int(row0),
+                  int(row1), C.byref(self.h)), "spmv_hip_csr_upload")
+        self.M, self.N = int(M), int(N)
+
+    @classmethod
+    def from_host(cls, csr: CsrHost, row0=0, row1=None):
+        return cls(csr.M, csr.N, csr.row_ptr, csr.col_idx, csr.values, row0, row1)
+
+    def info(self) -> dict:
+        out = nat.DevInfo()
+        _check(nat.lib().spmv_hip_csr_info(self.h, C.byref(out)), "spmv_hip_csr_info")
+        return out.as_dict()
+
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        if len(x) != self.N:
+            raise ValueError(f"x has {len(x)} entries, matrix has {self.N} columns")
+        _check(nat.lib().spmv_hip_csr_set_x(self.h, x.ctypes.data_as(C.c_void_p)), "csr_set_x")
+
+    def run(self, variant=CSR_AUTO):
+        _check(nat.lib().spmv_hip_csr_run(self.h, int(variant)), "spmv_hip_csr_run")
+
+    def get_y(self):
+        y = np.empty(self.M, dtype=self.dtype)
+        _check(nat.lib().spmv_hip_csr_get_y(self.h, y.ctypes.data_as(C.c_void_p)), "csr_get_y")
+        return y
+
+    def spmv(self, x, variant=CSR_AUTO):
+        self.set_x(x)
+        self.run(variant)
+        return self.get_y()
+
+    def run_on(self, d_x: int, d_y: int, variant=CSR_AUTO, stream: int = 0):
+        _check(nat.lib().spmv_hip_csr_run_on(self.h, int(variant), C.c_void_p(d_x),
+                                             C.c_void_p(d_y), C.c_void_p(stream)), "csr_run_on")
+
+    x_ptr = property(lambda s: nat.lib().spmv_hip_csr_x_ptr(s.h) or 0)
+    y_ptr = property(lambda s: nat.lib().spmv_hip_csr_y_ptr(s.h) or 0)
+
+    def time(self, variant=CSR_AUTO, warmup=5, iters=95):
+        """Per-launch kernel milliseconds, reference protocol (main_cuda.cu:159-200)."""
+        ms = np.zeros(iters, dtype=np.float32)
+        _check(nat.lib().spmv_hip_csr_time(self.h, int(variant), int(warmup), int(iters),
+                                           ms.ctypes.data_as(nat.c_float_p)), "csr_time")
+        return ms
+
+
+class HllDevice(_Handle):
+    """An HLL matrix resident in HBM as one flat slab."""
+
+    _free = "spmv_hip_hll_free"
+
+    def __init__(self, hll: HllHost):
+        super().__init__()
+        _check(nat.lib().spmv_hip_hll_upload(C.byref(hll.c), int(hll.M), int(hll.N),
+                                             C.byref(self.h)), "spmv_hip_hll_upload")
+        self.M, self.N = hll.M, hll.N
+
+    def info(self) -> dict:
+        out = nat.DevInfo()
+        _check(nat.lib().spmv_hip_hll_info(self.h, C.byref(out)), "spmv_hip_hll_info")
+        return out.as_dict()
+
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if len(x) != self.N:
+            raise ValueError(f"x has {len(x)} entries, matrix has {self.N} columns")
+        _check(nat.lib().spmv_hip_hll_set_x(self.h, x.ctypes.data_as(nat.c_double_p)), "hll_set_x")
+
+    def run(self, variant=HLL_AUTO):
+        _check(nat.lib().spmv_hip_hll_run(self.h, int(variant)), "spmv_hip_hll_run")
+
+    def get_y(self):
+        y = np.empty(self.M, dtype=np.float64)
+        _check(nat.lib().spmv_hip_hll_get_y(self.h, y.ctypes.data_as(nat.c_double_p)), "hll_get_y")
+        return y
+
+    def spmv(self, x, variant=HLL_AUTO):
+        self.set_x(x)
+        self.run(variant)
+        return self.get_y()
+
+    def time(self, variant=HLL_AUTO, warmup=5, iters=95):
+        ms = np.zeros(iters, dtype=np.float32)
+        _check(nat.lib().spmv_hip_hll_time(self.h, int(variant), int(warmup), int(iters),
+                                           ms.ctypes.data_as(nat.c_float_p)), "hll_time")
+        return ms
