@@ -1,0 +1,392 @@
+#!/usr/bin/env python3
+"""bench.py -- SpMV throughput on MI355X, the reference's protocol, one JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload nlpkkt|cant|cant_hll|powerlaw]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one SpMV y = A x over the whole matrix (x = 1, the reference's input,
+src/utility.c:18-22; inputs resident in HBM before the timed region).  For N > 1
+the rows are split into N contiguous nnz-balanced blocks (one process per GPU, the
+reference's own greedy, src/csr_matrix.c:167-266) and a step ends with the RCCL
+all-gatherv of y over xGMI, so the same total work is divided: strong scaling.
+
+Default workload = the configuration the 70 %-of-roofline target is quoted on:
+BASELINE.json configs[3] "nlpkkt120 fp64 CSR" run on however many GPUs were asked
+for.  SuiteSparse files are not available offline, so unless --mtx points at the
+real file a seeded, shape-matched stand-in is generated (M = 3 542 400 like
+nlpkkt120, ~98 M nnz, <= 28 per row; include/synth_matrix.h) and labelled as such.
+configs[1]/[2] (cant CSR / HLL: 49 MB, Infinity-Cache resident, ~6 us at the
+roofline, i.e. launch-bound) are reported in the same line under "also".
+
+Timing: W untimed steps, then exactly K steps between (barrier +
+torch.cuda.synchronize()) pairs, max over ranks.  Every timed launch is also
+bracketed by HIP events on the library's own stream (C side); roofline.achieved
+is algorithmic bytes / mean event time of the dominant kernel.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_DYNAMIC", "false")
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=95)      # reference: 95 timed ...
+    p.add_argument("--warmup", type=int, default=5)      # ... after ITERATION_SKIP = 5
+    p.add_argument("--workload", default="nlpkkt", choices=["nlpkkt", "cant", "cant_hll", "powerlaw"])
+    p.add_argument("--variant", default="auto")
+    p.add_argument("--mtx", default=os.environ.get("SPMV_MTX"))
+    p.add_argument("--grid", default=None, help="nx,ny,nz of the stand-in generator")
+    p.add_argument("--powerlaw-n", type=int, default=1 << 24)
+    p.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-also", action="store_true", help="skip the cant CSR/HLL side measurements")
+    p.add_argument("--cpu-iters", type=int, default=0, help="0 = size for ~10 s")
+    return p.parse_args()
+
+
+# ----------------------------------------------------------------- workloads
+def load_workload(args, sp, synth, rank, world):
+    """Returns dict(M, N, row_ptr (full), col, val (this rank's rows), bounds, name, data)."""
+    wl = args.workload
+    if args.mtx:
+        pre = sp.read_matrix_market(args.mtx)
+        csr = sp.convert_in_csr(pre)
+        M, N = csr.M, csr.N
+        row_ptr = np.array(csr.row_ptr)
+        bounds = sp.partition_rows(row_ptr, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        e0, e1 = row_ptr[r0], row_ptr[r1]
+        out = dict(M=M, N=N, row_ptr=row_ptr, col=np.array(csr.col_idx[e0:e1]),
+                   val=np.array(csr.values[e0:e1]), bounds=bounds,
+                   name=os.path.basename(args.mtx), data=f"file:{os.path.basename(args.mtx)}")
+        if wl == "cant_hll":
+            out["hll"] = sp.convert_to_hll(pre)
+        return out
+    if wl == "nlpkkt":
+        grid = tuple(int(v) for v in args.grid.split(",")) if args.grid else synth.KKT_GRID
+        M = sp.lib().synth_kkt_rows(*grid)
+        row_ptr = np.zeros(M + 1, np.int32)
+        assert sp.lib().synth_kkt_row_ptr(*grid, row_ptr.ctypes.data_as(sp._native.c_int_p)) == 0
+        bounds = sp.partition_rows(row_ptr, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        _, _, col, val = synth.kkt_like(grid, 2, r0, r1)
+        return dict(M=M, N=M, row_ptr=row_ptr, col=col, val=val, bounds=bounds,
+                    name=f"nlpkkt120-like stand-in {grid[0]}x{grid[1]}x{grid[2]}",
+                    data="synthetic (seeded KKT-shaped stencil matrix, seed 2)")
+    if wl in ("cant", "cant_hll"):
+        grid = tuple(int(v) for v in args.grid.split(",")) if args.grid else synth.FEM_GRID
+        M, row_ptr, col_all, val_all = synth.fem_like(grid, 1)
+        bounds = sp.partition_rows(row_ptr, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        e0, e1 = row_ptr[r0], row_ptr[r1]
+        out = dict(M=M, N=M, row_ptr=row_ptr, col=col_all[e0:e1], val=val_all[e0:e1], bounds=bounds,
+                   name=f"cant-like stand-in {grid[0]}x{grid[1]}x{grid[2]}x3",
+                   data="synthetic (seeded FEM-shaped stencil matrix, seed 1)")
+        if wl == "cant_hll":
+            from _bench_util import coo_of
+            r, c = coo_of(row_ptr, col_all)
+            out["hll"] = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, M, r, c, val_all))
+        return out
+    if wl == "powerlaw":
+        n = args.powerlaw_n
+        L = sp.lib()
+        row_ptr = np.zeros(n + 1, np.int32)
+        assert L.synth_powerlaw_row_ptr(n, 1 << 20, 5, row_ptr.ctypes.data_as(sp._native.c_int_p)) == 0
+        bounds = sp.partition_rows(row_ptr, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        _, _, col, val = synth.powerlaw(n, 1 << 20, 5, r0, r1)
+        return dict(M=n, N=n, row_ptr=row_ptr, col=col, val=val, bounds=bounds,
+                    name=f"power-law {n}x{n} fp32", data="synthetic (seeded power-law, seed 5)")
+    raise ValueError(wl)
+
+
+# ----------------------------------------------------------------- CPU baseline
+def cpu_baseline(wl, cpu_iters):
+    """The reference's OpenMP CSR kernel (spvm_csr_parallel, src/csr_matrix.c:294-313) on the
+    host cores of this box: the compiled reference itself when oracle/_ref travelled here
+    (kind "reference"), else this repo's restatement (kind "port")."""
+    import ctypes as C
+    from oracle.oracle import Oracle, Reference, have_reference
+    import sparsematrixvectormultiplication_amd as sp
+
+    row_ptr, col, val = wl["row_ptr"], wl["col_full"], wl["val_full"]
+    M, nnz = wl["M"], int(row_ptr[-1])
+    x = np.ones(wl["N"])
+    threads = min(os.cpu_count() or 1, M)
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    starts, ends = sp.prepare_thread_distribution(row_ptr, threads, nnz)
+    threads = len(starts)
+    val64 = np.ascontiguousarray(val, dtype=np.float64)
+    y = np.zeros(M)
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    if have_reference():
+        kind, fn = "reference", Reference().L.spvm_csr_parallel
+    else:
+        kind, fn = "port", Oracle().L.spvm_csr_parallel
+    args = (row_ptr.ctypes.data_as(ip), col.ctypes.data_as(ip), val64.ctypes.data_as(dp),
+            x.ctypes.data_as(dp), y.ctypes.data_as(dp), threads, starts.ctypes.data_as(ip),
+            ends.ctypes.data_as(ip))
+    t = time.perf_counter()
+    fn(*args)
+    first = time.perf_counter() - t
+    iters = cpu_iters or int(max(5, min(95, 10.0 / max(first, 1e-4))))
+    for _ in range(min(5, iters)):  # the reference's warm-up
+        fn(*args)
+    samples = []
+    for _ in range(iters):
+        t = time.perf_counter()
+        fn(*args)
+        samples.append(time.perf_counter() - t)
+    mean = float(np.mean(samples))
+    return {"value": round(2.0 * nnz / mean / 1e9, 3), "unit": "GFLOP/s", "cores": threads,
+            "kind": kind, "kernel": "spvm_csr_parallel (OpenMP, nnz-balanced row ranges)",
+            "ms_per_step": round(mean * 1e3, 4),
+            "sample": f"{iters} timed SpMVs over the whole {wl['name']} matrix "
+                      f"({nnz} nnz) after 5 warm-ups, x = 1"}, y
+
+
+# ----------------------------------------------------------------- side measurements
+def side_measurement(sp, synth, which, steps, warmup):
+    """cant-like CSR / HLL on this GPU (BASELINE configs[1], [2]); kernel-only event times."""
+    M, row_ptr, col, val = synth.fem_like()
+    nnz = int(row_ptr[-1])
+    x = np.ones(M)
+    if which == "cant_csr":
+        out = {}
+        with sp.CsrDevice(M, M, row_ptr, col, val) as dev:
+            dev.set_x(x)
+            info = dev.info()
+            for name, variant in (("wave_row", sp.CSR_WAVE_ROW), ("stream", sp.CSR_STREAM)):
+                ms = dev.time(variant, warmup, steps, zero_y=True)
+                out[name] = {"gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
+                             "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
+                             "us": round(float(ms.mean()) * 1e3, 2)}
+        return {"workload": "cant-like fp64 CSR (M=62451, nnz=%d; Infinity-Cache resident)" % nnz,
+                "algo_bytes": info["algo_bytes"], **out}
+    from _bench_util import coo_of
+    r, c = coo_of(row_ptr, col)
+    hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, M, r, c, val))
+    with sp.HllDevice(hll) as dev:
+        dev.set_x(x)
+        info = dev.info()
+        ms = dev.time(sp.HLL_LDS, warmup, steps, zero_y=True)
+    return {"workload": "cant-like fp64 HLL hack=32 (slots=%d; flops counted with the CSR nnz)" %
+            info["slots"], "algo_bytes": info["algo_bytes"],
+            "lds": {"gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
+                    "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
+                    "us": round(float(ms.mean()) * 1e3, 2)}}
+
+
+# ----------------------------------------------------------------- main
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch  # first, so that one HIP runtime serves torch and libspmv_amd.so alike
+    import torch.distributed as dist
+    import sparsematrixvectormultiplication_amd as sp
+    from sparsematrixvectormultiplication_amd import synth
+    from sparsematrixvectormultiplication_amd.distributed import NativeComm, allgatherv_rows_torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
+    torch.cuda.set_device(local_rank)
+    sp.hip_init(local_rank)
+    dev_name, cus, _ = sp.device_name()
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sp.hip_sync()
+
+    t0 = time.time()
+    wl = load_workload(args, sp, synth, rank, world)
+    M, N, bounds = wl["M"], wl["N"], wl["bounds"]
+    nnz_total = int(wl["row_ptr"][-1])
+    log(f"[rank {rank}] {wl['name']}: M={M} nnz={nnz_total} built in {time.time() - t0:.1f}s on {dev_name}")
+
+    hll_mode = args.workload == "cant_hll"
+    if hll_mode and world > 1:
+        raise SystemExit("the HLL workload is single-GPU (BASELINE configs[2])")
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    if hll_mode:
+        dev = sp.HllDevice(wl["hll"])
+        variant = sp.HLL_AUTO if args.variant == "auto" else sp.HLL_VARIANTS[args.variant]
+        vb = 8
+    else:
+        e0 = int(wl["row_ptr"][r0])
+        rp_local = np.concatenate([np.zeros(r0, np.int32), wl["row_ptr"][r0:r1 + 1] - e0,
+                                   np.full(M - r1, wl["row_ptr"][r1] - e0, np.int32)])
+        dev = sp.CsrDevice(M, N, rp_local, wl["col"], wl["val"], r0, r1)
+        variant = sp.CSR_AUTO if args.variant == "auto" else sp.CSR_VARIANTS[args.variant]
+        vb = 4 if wl["val"].dtype == np.float32 else 8
+    info = dev.info()
+    x = np.ones(N, dtype=np.float32 if vb == 4 else np.float64)
+    dev.set_x(x)
+
+    # the exchange step (N > 1): RCCL all-gatherv of y
+    comm, exchange = None, "none"
+    if world > 1:
+        exchange = args.exchange
+        if exchange == "rccl":
+            try:
+                def share(ident):
+                    box = [ident]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+                comm = NativeComm(rank, world, share)
+            except Exception as exc:  # both transports are RCCL; fall back to torch's
+                log(f"[rank {rank}] native RCCL communicator unavailable ({exc}); using torch.distributed")
+                exchange = "torch"
+        if exchange == "torch":
+            y_t = torch.zeros(M, dtype=torch.float32 if vb == 4 else torch.float64, device="cuda")
+            x_t = torch.ones(N, dtype=y_t.dtype, device="cuda")
+            stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- timed region
+    K, W = args.steps, args.warmup
+    ms_kernel = ms_xchg = None
+    if world == 1:
+        dev.time(variant, W, 1, zero_y=False) if W else None
+        barrier_sync()
+        t = time.perf_counter()
+        ms_kernel = dev.time(variant, 0, K, zero_y=False)  # K launches, HIP events around each
+        barrier_sync()
+        wall = time.perf_counter() - t
+    elif exchange == "rccl":
+        dev.step_time(bounds, variant, W, 1)
+        barrier_sync()
+        t = time.perf_counter()
+        ms_kernel, ms_xchg = dev.step_time(bounds, variant, 0, K)
+        barrier_sync()
+        wall = time.perf_counter() - t
+    else:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]
+
+        def step(i=None):
+            if i is not None:
+                ev[3 * i].record()
+            dev.run_on(x_t.data_ptr(), y_t.data_ptr(), variant, stream)
+            if i is not None:
+                ev[3 * i + 1].record()
+            allgatherv_rows_torch(y_t, bounds)
+            if i is not None:
+                ev[3 * i + 2].record()
+        for _ in range(W):
+            step()
+        barrier_sync()
+        t = time.perf_counter()
+        for i in range(K):
+            step(i)
+        barrier_sync()
+        wall = time.perf_counter() - t
+        ms_kernel = np.array([ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)])
+        ms_xchg = np.array([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)])
+
+    stats = torch.tensor([wall, float(np.mean(ms_kernel)), float(np.mean(ms_xchg)) if ms_xchg is not None else 0.0,
+                          float(info["algo_bytes"]), float(info["nz"])], dtype=torch.float64)
+    if world > 1:
+        stats = stats.cuda()
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        per_rank = torch.stack(gathered).cpu().numpy()
+    else:
+        per_rank = stats.numpy()[None, :]
+    wall_max = float(per_rank[:, 0].max())
+
+    # ---- parity spot check on this rank's rows (checker: the oracle)
+    y_gpu = dev.get_y()
+    result = None
+    if rank == 0:
+        ms_step = wall_max / K * 1e3
+        gflops = 2.0 * nnz_total / (wall_max / K) / 1e9
+        algo_total = float(per_rank[:, 3].sum())
+        # dominant kernel = this rank's SpMV kernel; slowest rank sets the pace
+        slow = int(np.argmax(per_rank[:, 1]))
+        k_ms = float(per_rank[slow, 1])
+        achieved = per_rank[slow, 3] / (k_ms * 1e-3) / 1e9
+        kernel_name = ("hll_lds" if hll_mode else
+                       {0: "csr_stream", 1: "csr_thread_row", 2: "csr_vector<64,2>", 3: "csr_vector<L,1>",
+                        4: "csr_stream"}[variant if variant else info["auto_variant"]])
+        result = {
+            "metric": "SpMV GFLOP/s (2*nnz flops / step time); achieved HBM GB/s and % of 8 TB/s alongside",
+            "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(ms_step, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if vb == 4 else "f64", "data": wl["data"],
+            "hbm_gbps": round(algo_total / (wall_max / K) / 1e9, 1),
+            "hbm_pct_of_8TBs": round(algo_total / (wall_max / K) / 1e9 / HBM_PEAK_GBPS * 100, 2),
+            "config": {"workload": wl["name"] + (" HLL hack=32" if hll_mode else " CSR"),
+                       "rows": M, "cols": N, "nnz": nnz_total, "x": "ones",
+                       "kernel": kernel_name, "parallelism": f"row-block x{world}" if world > 1 else "1 GPU",
+                       "exchange": {"none": "none", "rccl": "RCCL all-gatherv(y), C-ABI communicator",
+                                    "torch": "RCCL all-gatherv(y) via torch.distributed"}[exchange],
+                       "nnz_imbalance_max_over_mean": round(float(per_rank[:, 4].max() / per_rank[:, 4].mean()), 4),
+                       "device": dev_name},
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": int(per_rank[slow, 3]),
+                         "kernel_ms_mean": round(k_ms, 5),
+                         "kernel_ms_min": round(float(np.min(ms_kernel)), 5) if slow == 0 else None},
+        }
+        if world > 1:
+            result["per_step_ms"] = {"kernel_max_over_ranks": round(float(per_rank[:, 1].max()), 5),
+                                     "allgatherv_max_over_ranks": round(float(per_rank[:, 2].max()), 5)}
+
+    # CPU baseline + oracle check: rank 0, N = 1 only (bounded, ~10 s)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not hll_mode and vb == 8:
+        wl["col_full"], wl["val_full"] = wl["col"], wl["val"]
+        cb, y_cpu = cpu_baseline(wl, args.cpu_iters)
+        result["cpu_baseline"] = cb
+        scale = max(float(np.max(np.abs(y_cpu))), 1e-300)
+        result["parity_vs_cpu_reference"] = {"max_abs_diff_over_max_abs": float(np.max(np.abs(y_gpu - y_cpu)) / scale),
+                                             "gate": 1e-10}
+    if rank == 0 and world == 1 and not args.no_also and args.workload == "nlpkkt":
+        dev.close()
+        try:
+            result["also"] = [side_measurement(sp, synth, "cant_csr", K, W),
+                              side_measurement(sp, synth, "cant_hll", K, W)]
+        except Exception as exc:  # side numbers must never lose the headline line
+            result["also"] = [{"error": str(exc)}]
+    if comm is not None:
+        comm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -121,10 +121,13 @@ void *spmv_hip_csr_y_ptr(spmv_csr_dev *m);
  * caller's stream (NULL = library stream) */
 int spmv_hip_csr_run_on(spmv_csr_dev *m, int variant, const void *d_x, void *d_y, void *stream);
 
-/* The reference's timing protocol (main_cuda.cu:159-200): per iteration zero
- * y, record an event, launch, record an event; `warmup` untimed iterations
- * first.  ms_each receives `iters` kernel durations in milliseconds. */
-int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, float *ms_each);
+/* The reference's timing protocol (main_cuda.cu:159-200): per iteration
+ * [zero y if zero_y], record an event, launch, record an event; `warmup`
+ * untimed iterations first.  ms_each receives `iters` kernel durations in
+ * milliseconds.  The kernels overwrite every row of y, so zero_y only matters
+ * for protocol fidelity (the memset sits outside the event pair either way). */
+int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, int zero_y,
+                      float *ms_each);
 
 /* ---- HLL --------------------------------------------------------------- */
 /* total_rows = the matrix' M (the last hack may hold fewer than 32 rows). */
@@ -135,7 +138,8 @@ int spmv_hip_hll_set_x(spmv_hll_dev *m, const double *x_host);
 int spmv_hip_hll_run(spmv_hll_dev *m, int variant);
 int spmv_hip_hll_get_y(spmv_hll_dev *m, double *y_host);
 int spmv_hip_hll_run_on(spmv_hll_dev *m, int variant, const void *d_x, void *d_y, void *stream);
-int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, float *ms_each);
+int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, int zero_y,
+                      float *ms_each);
 
 /* ---- multi-GPU: one process per GPU, rows split by nnz ------------------ */
 /* Contiguous nnz-balanced row split for `parts` GPUs: the reference's greedy
@@ -156,6 +160,11 @@ int spmv_hip_comm_destroy(void);
  * grouped set of ncclBroadcast calls on `stream` (NULL = library stream).
  * value_bytes is 8 (fp64) or 4 (fp32). */
 int spmv_hip_comm_allgatherv(void *d_y, const int *bounds, int value_bytes, void *stream);
+/* One multi-GPU step, timed: SpMV on this rank's rows then the all-gatherv of
+ * the library-owned y, both on the library stream, events around each part.
+ * ms_kernel / ms_exchange receive `iters` values (either may be NULL). */
+int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *bounds, int warmup, int iters,
+                           float *ms_kernel, float *ms_exchange);
 
 #ifdef __cplusplus
 }

@@ -155,7 +155,9 @@ _PROTOTYPES = {
     "spmv_hip_csr_x_ptr": (C.c_void_p, [C.c_void_p]),
     "spmv_hip_csr_y_ptr": (C.c_void_p, [C.c_void_p]),
     "spmv_hip_csr_run_on": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "spmv_hip_csr_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]),
+    "spmv_hip_csr_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p]),
+    "spmv_hip_csr_step_time": (C.c_int, [C.c_void_p, C.c_int, c_int_p, C.c_int, C.c_int, c_float_p,
+                                         c_float_p]),
     "spmv_hip_hll_upload": (C.c_int, [C.POINTER(HLLMatrix), C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
     "spmv_hip_hll_free": (None, [C.c_void_p]),
@@ -164,7 +166,7 @@ _PROTOTYPES = {
     "spmv_hip_hll_run": (C.c_int, [C.c_void_p, C.c_int]),
     "spmv_hip_hll_get_y": (C.c_int, [C.c_void_p, c_double_p]),
     "spmv_hip_hll_run_on": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "spmv_hip_hll_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]),
+    "spmv_hip_hll_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p]),
     "spmv_hip_partition_rows": (C.c_int, [C.c_int, c_int_p, C.c_int, c_int_p]),
     "spmv_hip_comm_get_id": (C.c_int, [C.c_void_p]),
     "spmv_hip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -280,6 +280,10 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     const long long nz = (long long)e1 - e0;
     if (nz < 0) return fail("csr_upload: row_ptr is not monotone");
     if (nz > 0 && (!col_idx || !values)) return fail("csr_upload: col_idx / values are NULL");
+    // a column index outside [0, N) would make the kernels gather out of bounds
+    for (int e = e0; e < e1; ++e)
+        if ((unsigned)col_idx[e] >= (unsigned)N)
+            return fail("csr_upload: column index %d at entry %d is outside [0, %d)", col_idx[e], e, N);
 
     spmv_csr_dev *m = new (std::nothrow) spmv_csr_dev();
     if (!m) return fail("csr_upload: out of host memory");
@@ -493,6 +497,7 @@ namespace {
 // events around each launch on the stream the kernel runs on
 template <typename Launch, typename Zero>
 int time_loop(int warmup, int iters, float *ms_each, Launch launch, Zero zero_y) {
+    // zero_y() is a no-op when the caller did not ask for the reference's memset
     if (iters <= 0 || !ms_each) return fail("time: iters must be > 0 and ms_each non-NULL");
     std::vector<hipEvent_t> ev((size_t)iters * 2);
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
@@ -518,13 +523,14 @@ int time_loop(int warmup, int iters, float *ms_each, Launch launch, Zero zero_y)
 
 }  // namespace
 
-extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, float *ms_each) {
+extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, int zero_y,
+                                 float *ms_each) {
     if (need_device()) return -1;
     if (!m) return fail("csr_time: NULL handle");
     return time_loop(
         warmup, iters, ms_each, [&] { return csr_launch_any(m, variant, m->x, m->y, g_stream); },
         [&]() -> int {
-            HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M_total * m->value_bytes, g_stream));
+            if (zero_y) HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M_total * m->value_bytes, g_stream));
             return 0;
         });
 }
@@ -566,6 +572,9 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
             return fail("hll_upload: hack %d is malformed", h);
         mz[h] = b->MAXNZ;
         const long long s = (long long)b->M * b->MAXNZ;
+        for (long long k = 0; k < s; ++k)
+            if ((unsigned)b->JA[k] >= (unsigned)N)
+                return fail("hll_upload: column index %d in hack %d is outside [0, %d)", b->JA[k], h, N);
         true_slots += s;
         off[h + 1] = off[h] + ((s + 1) & ~1LL);  // next hack starts on an even slot
     }
@@ -713,13 +722,14 @@ extern "C" int spmv_hip_hll_run_on(spmv_hll_dev *m, int variant, const void *d_x
     return hll_launch(m, variant, (const double *)d_x, (double *)d_y, stream ? (hipStream_t)stream : g_stream);
 }
 
-extern "C" int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, float *ms_each) {
+extern "C" int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, int zero_y,
+                                 float *ms_each) {
     if (need_device()) return -1;
     if (!m) return fail("hll_time: NULL handle");
     return time_loop(
         warmup, iters, ms_each, [&] { return hll_launch(m, variant, m->x, m->y, g_stream); },
         [&]() -> int {
-            HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M * 8, g_stream));
+            if (zero_y) HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M * 8, g_stream));
             return 0;
         });
 }
@@ -793,4 +803,33 @@ extern "C" int spmv_hip_comm_allgatherv(void *d_y, const int *bounds, int value_
     }
     NCCL_TRY(ncclGroupEnd());
     return 0;
+}
+
+extern "C" int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *bounds, int warmup,
+                                      int iters, float *ms_kernel, float *ms_exchange) {
+    if (need_device()) return -1;
+    if (!m || !bounds) return fail("csr_step_time: NULL argument");
+    if (iters <= 0) return fail("csr_step_time: iters must be > 0");
+    std::vector<hipEvent_t> ev((size_t)iters * 3);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = 0;
+    for (int i = -warmup; i < iters && !rc; ++i) {
+        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i], g_stream));
+        rc = csr_launch_any(m, variant, m->x, m->y, g_stream);
+        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 1], g_stream));
+        if (!rc && g_comm) rc = spmv_hip_comm_allgatherv(m->y, bounds, m->value_bytes, g_stream);
+        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 2], g_stream));
+    }
+    if (!rc) {
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        for (int i = 0; i < iters; ++i) {
+            float a = 0, b = 0;
+            HIP_TRY(hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
+            HIP_TRY(hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
+            if (ms_kernel) ms_kernel[i] = a;
+            if (ms_exchange) ms_exchange[i] = b;
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
 }

@@ -140,12 +140,23 @@ class CsrDevice(_Handle):
     x_ptr = property(lambda s: nat.lib().spmv_hip_csr_x_ptr(s.h) or 0)
     y_ptr = property(lambda s: nat.lib().spmv_hip_csr_y_ptr(s.h) or 0)
 
-    def time(self, variant=CSR_AUTO, warmup=5, iters=95):
+    def time(self, variant=CSR_AUTO, warmup=5, iters=95, zero_y=True):
         """Per-launch kernel milliseconds, reference protocol (main_cuda.cu:159-200)."""
         ms = np.zeros(iters, dtype=np.float32)
         _check(nat.lib().spmv_hip_csr_time(self.h, int(variant), int(warmup), int(iters),
-                                           ms.ctypes.data_as(nat.c_float_p)), "csr_time")
+                                           int(bool(zero_y)), ms.ctypes.data_as(nat.c_float_p)),
+               "csr_time")
         return ms
+
+    def step_time(self, bounds, variant=CSR_AUTO, warmup=5, iters=95):
+        """Multi-GPU step (SpMV + all-gatherv of y): per-step kernel and exchange ms."""
+        b = np.ascontiguousarray(bounds, dtype=np.int32)
+        mk, mx = np.zeros(iters, np.float32), np.zeros(iters, np.float32)
+        _check(nat.lib().spmv_hip_csr_step_time(self.h, int(variant), b.ctypes.data_as(nat.c_int_p),
+                                                int(warmup), int(iters),
+                                                mk.ctypes.data_as(nat.c_float_p),
+                                                mx.ctypes.data_as(nat.c_float_p)), "csr_step_time")
+        return mk, mx
 
 
 class HllDevice(_Handle):
@@ -183,8 +194,9 @@ class HllDevice(_Handle):
         self.run(variant)
         return self.get_y()
 
-    def time(self, variant=HLL_AUTO, warmup=5, iters=95):
+    def time(self, variant=HLL_AUTO, warmup=5, iters=95, zero_y=True):
         ms = np.zeros(iters, dtype=np.float32)
         _check(nat.lib().spmv_hip_hll_time(self.h, int(variant), int(warmup), int(iters),
-                                           ms.ctypes.data_as(nat.c_float_p)), "hll_time")
+                                           int(bool(zero_y)), ms.ctypes.data_as(nat.c_float_p)),
+               "hll_time")
         return ms
