@@ -36,7 +36,38 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _host_cores():
+    """Cores this process may use, read BEFORE any OpenMP runtime starts (with
+    OMP_PROC_BIND the runtime pins the main thread, after which the affinity mask of
+    the process reads as one core) and capped by the cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+HOST_CORES = _host_cores()
+
 import numpy as np  # noqa: E402
+
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json,
+    written by tools/prof_traffic.py: FETCH_SIZE doubled per the gfx950 correction in
+    MI355X_MICROARCH.md + WRITE_SIZE), for the same kernel on the same workload; else None."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return table.get(f"{kernel}|{workload}")
+    except (OSError, ValueError):
+        return None
+
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
 
@@ -130,11 +161,7 @@ def cpu_baseline(wl, cpu_iters):
     row_ptr, col, val = wl["row_ptr"], wl["col_full"], wl["val_full"]
     M, nnz = wl["M"], int(row_ptr[-1])
     x = np.ones(wl["N"])
-    threads = min(os.cpu_count() or 1, M)
-    try:
-        threads = min(threads, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
+    threads = min(HOST_CORES, M)
     starts, ends = sp.prepare_thread_distribution(row_ptr, threads, nnz)
     threads = len(starts)
     val64 = np.ascontiguousarray(val, dtype=np.float64)
@@ -159,9 +186,19 @@ def cpu_baseline(wl, cpu_iters):
         fn(*args)
         samples.append(time.perf_counter() - t)
     mean = float(np.mean(samples))
+    # the oracle kernel itself (K1, one core), three runs
+    serial_fn = (Reference() if kind == "reference" else Oracle()).L.csr_matrix_vector_mult
+    ys = np.zeros(M)
+    serial = []
+    for _ in range(3):
+        ys[:] = 0.0
+        t = time.perf_counter()
+        serial_fn(M, args[0], args[1], args[2], args[3], ys.ctypes.data_as(dp))
+        serial.append(time.perf_counter() - t)
     return {"value": round(2.0 * nnz / mean / 1e9, 3), "unit": "GFLOP/s", "cores": threads,
             "kind": kind, "kernel": "spvm_csr_parallel (OpenMP, nnz-balanced row ranges)",
             "ms_per_step": round(mean * 1e3, 4),
+            "serial_csr_gflops_1core": round(2.0 * nnz / min(serial) / 1e9, 3),
             "sample": f"{iters} timed SpMVs over the whole {wl['name']} matrix "
                       f"({nnz} nnz) after 5 warm-ups, x = 1"}, y
 
@@ -213,7 +250,8 @@ def main():
     import torch.distributed as dist
     import sparsematrixvectormultiplication_amd as sp
     from sparsematrixvectormultiplication_amd import synth
-    from sparsematrixvectormultiplication_amd.distributed import NativeComm, allgatherv_rows_torch
+    from sparsematrixvectormultiplication_amd.distributed import (NativeComm, allgatherv_rows_torch,
+                                                                 local_row_ptr)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
@@ -244,10 +282,7 @@ def main():
         variant = sp.HLL_AUTO if args.variant == "auto" else sp.HLL_VARIANTS[args.variant]
         vb = 8
     else:
-        e0 = int(wl["row_ptr"][r0])
-        rp_local = np.concatenate([np.zeros(r0, np.int32), wl["row_ptr"][r0:r1 + 1] - e0,
-                                   np.full(M - r1, wl["row_ptr"][r1] - e0, np.int32)])
-        dev = sp.CsrDevice(M, N, rp_local, wl["col"], wl["val"], r0, r1)
+        dev = sp.CsrDevice(M, N, local_row_ptr(wl["row_ptr"], r0, r1), wl["col"], wl["val"], r0, r1)
         variant = sp.CSR_AUTO if args.variant == "auto" else sp.CSR_VARIANTS[args.variant]
         vb = 4 if wl["val"].dtype == np.float32 else 8
     info = dev.info()
@@ -355,7 +390,7 @@ def main():
                        "device": dev_name},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None,
+                         "traffic": measured_traffic(kernel_name, wl["name"]),
                          "algorithmic_bytes_per_launch": int(per_rank[slow, 3]),
                          "kernel_ms_mean": round(k_ms, 5),
                          "kernel_ms_min": round(float(np.min(ms_kernel)), 5) if slow == 0 else None},
@@ -385,7 +420,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result, default=lambda o: o.item() if hasattr(o, "item") else str(o)), flush=True)
 
 
 if __name__ == "__main__":

@@ -88,6 +88,13 @@ int spmv_hip_device_name(char *buf, size_t len, int *compute_units, long long *h
  * (answers clear_gpu_cache / clear_cache_kernel, cuda_src/utility.cu:140-175;
  * the reference's 64 MiB is far below MI355X's 256 MiB Infinity Cache). */
 int spmv_hip_flush_cache(size_t bytes);
+/* Kernel tuning knobs, for A/B measurements: "stream_cap" (2048 | 4096 | 8192 nnz staged
+ * per csr_stream workgroup; read at upload), "stream_nt" (0/1 non-temporal
+ * col/val loads), "stream_xcd" (0/1 XCD-contiguous workgroup order), "stream_block" (256 | 512 | 1024
+ * threads), "stream_kind" (0 = one workgroup per block, products summed out of
+ * LDS; 1 = rows walked out of LDS by neighbouring lanes; 2 = persistent,
+ * double-buffered product kernel), "pipe_wgs_per_cu" (grid of kind 2). */
+int spmv_hip_set_tuning(const char *key, int value);
 
 /* raw device buffers, for callers that keep x / y on the device themselves */
 int spmv_hip_malloc(void **dptr, size_t bytes);

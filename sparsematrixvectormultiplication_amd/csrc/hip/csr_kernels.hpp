@@ -24,11 +24,10 @@
 namespace spmv {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
-constexpr int kStreamCap = 2048;     // nnz staged per workgroup (16 KiB of fp64 products)
+constexpr int kStreamCapMax = 8192;  // largest nnz stage per workgroup (64 KiB of fp64 products)
 constexpr int kStreamUnit = 2 * kBlock;  // nnz one pass of the workgroup covers
 constexpr int kStreamRowsCap = 1024; // rows per workgroup (bounds the empty-row case)
 constexpr int kLongPiece = 8192;     // nnz per workgroup when one row is split
-constexpr int kLongFlag = 0x40000000;
 
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -43,6 +42,17 @@ template <bool NT, typename V>
 __device__ __forceinline__ V stream_load(const V *p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
+}
+
+// x[c] with a wave-uniform base and a 32-bit byte offset: the compiler emits the
+// `global_load v, v_off, s[base:base+1]` form (one address VGPR per lane instead of
+// two and no 64-bit VALU address math).  The gathers are what keeps the texture
+// addresser busy in these kernels, so their address payload matters.  Needs
+// N * sizeof(T) < 4 GiB, which upload checks.
+template <typename T>
+__device__ __forceinline__ T gather(const T *__restrict__ x, int c) {
+    const unsigned off = (unsigned)c * (unsigned)sizeof(T);
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(x) + off);
 }
 
 // Workgroup ids are dealt round-robin over the 8 XCDs; give each XCD one
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void csr_thread_row(int M, const int *__res
     if (r >= M) return;
     T acc = 0;
     const int stop = row_ptr[r + 1];
-    for (int e = row_ptr[r]; e < stop; ++e) acc += val[e] * x[col[e]];
+    for (int e = row_ptr[r]; e < stop; ++e) acc += val[e] * gather(x, col[e]);
     y[r] = acc;
 }
 
@@ -85,13 +95,13 @@ __global__ __launch_bounds__(kBlock) void csr_vector(int M, const int *__restric
     if (r < M) {
         const int begin = row_ptr[r], stop = row_ptr[r + 1];
         if constexpr (VEC == 1) {
-            for (int e = begin + lane; e < stop; e += L) acc += val[e] * x[col[e]];
+            for (int e = begin + lane; e < stop; e += L) acc += val[e] * gather(x, col[e]);
         } else {
             for (int e = (begin & ~1) + 2 * lane; e < stop; e += 2 * L) {
                 const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(col + e));
                 const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(val + e));
-                const T p0 = e >= begin ? v.x * x[c.x] : T(0);
-                const T p1 = e + 1 < stop ? v.y * x[c.y] : T(0);
+                const T p0 = e >= begin ? v.x * gather(x, c.x) : T(0);
+                const T p1 = e + 1 < stop ? v.y * gather(x, c.y) : T(0);
                 acc += p0;
                 acc += p1;
             }
@@ -102,103 +112,53 @@ __global__ __launch_bounds__(kBlock) void csr_vector(int M, const int *__restric
 }
 
 // -------------------------------------------------------------------- stream
-// Workgroup b owns rows [desc[b].x, desc[b+1].x) whose entries start at
-// desc[b].y; descriptors are built on the host at upload (csr_build_blocks)
-// so that the entries of a workgroup fit the LDS stage.  A row longer than
-// the stage is cut into pieces of kLongPiece entries (desc.x carries
-// kLongFlag, desc.z the slot of the piece's partial sum); csr_long_finish
-// then adds the pieces of each such row in slot order, so results do not
-// depend on scheduling (no atomics).
-template <typename T, bool NT, bool XCD>
-__global__ __launch_bounds__(kBlock) void csr_stream(int num_blocks, int per_xcd,
-                                                     const int4 *__restrict__ desc,
-                                                     const int *__restrict__ row_ptr,
-                                                     const int *__restrict__ col,
-                                                     const T *__restrict__ val,
-                                                     const T *__restrict__ x, T *__restrict__ y,
-                                                     T *__restrict__ partial) {
-    using V2 = typename vec2<T>::type;
-    constexpr int kUnits = kStreamCap / kStreamUnit;
-    __shared__ T prod[kStreamCap];
-    __shared__ T wave_part[kBlock / 64];
+// Upload cuts the rows into workgroup-sized blocks (csr_build_blocks): block b
+// is desc[b] = {first row, first entry, rows, end entry}; its entries fit the LDS stage
+// (CAP).  A row longer than the stage is left out of the blocks and handled by
+// csr_long_pieces / csr_long_finish (pieces of kLongPiece entries whose partial
+// sums are added in slot order, so results do not depend on scheduling: no
+// atomics).
+//
+// All stream kernels stage with unconditional loads: col/val carry >= CAP
+// entries of zero padding behind the last nonzero; entries past a block's end
+// belong to later rows and their products land in LDS slots no row of the block
+// reads.
 
-    const int b = XCD ? xcd_contiguous(blockIdx.x, per_xcd) : (int)blockIdx.x;
-    if (b >= num_blocks) return;  // whole workgroup leaves together
+// Sum prod[lo + lane], prod[lo + lane + lanes], ... below hi with four
+// independent accumulators so that four LDS reads are in flight per lane
+// instead of a read -> wait -> add chain.
+template <typename T>
+__device__ __forceinline__ T lds_strided_sum(const T *prod, int lo, int hi, int lane, int lanes) {
+    T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int k = lo + lane;
+    for (; k + 3 * lanes < hi; k += 4 * lanes) {
+        a0 += prod[k];
+        a1 += prod[k + lanes];
+        a2 += prod[k + 2 * lanes];
+        a3 += prod[k + 3 * lanes];
+    }
+    for (; k < hi; k += lanes) a0 += prod[k];
+    return (a0 + a1) + (a2 + a3);
+}
+
+// lanes per row for the LDS sum: the largest power of two that still gives
+// every row of the block its own lane group in one pass
+template <int BLOCK>
+__device__ __forceinline__ int lanes_for_rows(int nrows) {
+    if (nrows > BLOCK / 2) return 1;
+    const int l = 1 << (31 - __clz(BLOCK / nrows));
+    return l > 64 ? 64 : l;
+}
+
+// Rows [r0, r0 + nrows) out of the staged products: lane groups of `lanes`.
+template <typename T, int BLOCK>
+__device__ __forceinline__ void sum_rows_from_lds(const T *prod, const int *__restrict__ row_ptr,
+                                                  T *__restrict__ y, int r0, int nrows, int base,
+                                                  int lanes, int seg_lo, int seg_hi) {
     const int t = threadIdx.x;
-    const int4 d0 = desc[b];
-    const int4 d1 = desc[b + 1];
-    const int n0 = d0.y, n1 = d1.y;
-
-    if (d0.x & kLongFlag) {
-        // one piece of a long row: strided register accumulation, no staging
-        T acc = 0;
-        for (int e = (n0 & ~1) + 2 * t; e < n1; e += kStreamUnit) {
-            const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(col + e));
-            const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(val + e));
-            const T p0 = e >= n0 ? v.x * x[c.x] : T(0);
-            const T p1 = e + 1 < n1 ? v.y * x[c.y] : T(0);
-            acc += p0;
-            acc += p1;
-        }
-        acc = group_sum<64>(acc);
-        if ((t & 63) == 0) wave_part[t >> 6] = acc;
-        __syncthreads();
-        if (t == 0) {
-            T s = wave_part[0];
-            for (int w = 1; w < kBlock / 64; ++w) s += wave_part[w];
-            partial[d0.z] = s;
-        }
-        return;
-    }
-
-    const int r0 = d0.x, r1 = d1.x & ~kLongFlag;
-    const int nrows = r1 - r0;
-    const int base = n0 & ~1;
-
-    // lanes per row for the LDS sum: the largest power of two that still
-    // gives every row of the block its own lane group in one pass
-    int lanes = 1;
-    if (nrows <= kBlock / 2) {
-        const int q = kBlock / (nrows > 0 ? nrows : 1);
-        lanes = 1 << (31 - __clz(q));
-        if (lanes > 64) lanes = 64;
-    }
-    const int rows_per_pass = kBlock / lanes;
+    const int rows_per_pass = BLOCK / lanes;
     const int my_row = t / lanes, my_lane = t % lanes;
-
-    // row extents of the first pass: issued before the stream so their latency
-    // overlaps it
-    int seg_lo = 0, seg_hi = 0;
-    if (my_row < nrows) {
-        seg_lo = row_ptr[r0 + my_row] - base;
-        seg_hi = row_ptr[r0 + my_row + 1] - base;
-    }
-
-    // stage: all loads of the block are independent and issued back to back
-    v2i c[kUnits];
-    V2 v[kUnits];
-#pragma unroll
-    for (int u = 0; u < kUnits; ++u) {
-        const int e = base + u * kStreamUnit + 2 * t;
-        if (e < n1) {
-            c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e));
-            v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e));
-        } else {
-            c[u] = v2i{0, 0};
-            v[u] = V2{0, 0};
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < kUnits; ++u) {
-        V2 p;
-        p.x = v[u].x * x[c[u].x];
-        p.y = v[u].y * x[c[u].y];
-        *reinterpret_cast<V2 *>(&prod[u * kStreamUnit + 2 * t]) = p;
-    }
-    __syncthreads();
-
-    // sum the rows out of LDS; all lanes stay in the loop (group_sum needs them)
-    for (int first = 0; first < nrows; first += rows_per_pass) {
+    for (int first = 0; first < nrows; first += rows_per_pass) {  // all lanes stay in the loop
         const int row = first + my_row;
         if (first > 0) {
             seg_lo = seg_hi = 0;
@@ -207,10 +167,305 @@ __global__ __launch_bounds__(kBlock) void csr_stream(int num_blocks, int per_xcd
                 seg_hi = row_ptr[r0 + row + 1] - base;
             }
         }
-        T acc = 0;
-        for (int k = seg_lo + my_lane; k < seg_hi; k += lanes) acc += prod[k];
+        T acc = lds_strided_sum(prod, seg_lo, seg_hi, my_lane, lanes);
         acc = group_sum_rt(acc, lanes);
         if (my_lane == 0 && row < nrows) y[r0 + row] = acc;
+    }
+}
+
+// One workgroup per block: stage products, sum rows.
+template <typename T, bool NT, bool XCD, int CAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int per_xcd,
+                                                    const int4 *__restrict__ desc,
+                                                    const int *__restrict__ row_ptr,
+                                                    const int *__restrict__ col,
+                                                    const T *__restrict__ val,
+                                                    const T *__restrict__ x, T *__restrict__ y) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * BLOCK;  // entries one pass of the workgroup covers
+    constexpr int kUnits = CAP / kUnit;
+    __shared__ T prod[CAP];
+
+    const int b = XCD ? xcd_contiguous(blockIdx.x, per_xcd) : (int)blockIdx.x;
+    if (b >= num_blocks) return;  // whole workgroup leaves together
+    const int t = threadIdx.x;
+    const int4 d = desc[b];
+    const int r0 = d.x, nrows = d.z;
+    const int base = d.y & ~1;
+
+    // row extents of the first pass go out first so they are back early
+    const int lanes = lanes_for_rows<BLOCK>(nrows);
+    int seg_lo = 0, seg_hi = 0;
+    if (t / lanes < nrows) {
+        seg_lo = row_ptr[r0 + t / lanes];
+        seg_hi = row_ptr[r0 + t / lanes + 1];
+    }
+
+    const int e_first = base + 2 * t;
+    const int units = (d.w - base + kUnit - 1) / kUnit;  // wave-uniform
+    if (units == kUnits) {
+        // a full block: everything straight-line
+        v2i c[kUnits];
+        V2 v[kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kUnit));
+            v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+        }
+        T xv[2 * kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            xv[2 * u] = gather(x, c[u].x);
+            xv[2 * u + 1] = gather(x, c[u].y);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            V2 p;
+            p.x = v[u].x * xv[2 * u];
+            p.y = v[u].y * xv[2 * u + 1];
+            *reinterpret_cast<V2 *>(&prod[u * kUnit + 2 * t]) = p;
+        }
+    } else {
+        // a block cut short by its row cap or by the end of the matrix: only the
+        // units it really has (scalar loop, no wasted traffic)
+        for (int u = 0; u < units; ++u) {
+            const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kUnit));
+            const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+            V2 p;
+            p.x = v.x * gather(x, c.x);
+            p.y = v.y * gather(x, c.y);
+            *reinterpret_cast<V2 *>(&prod[u * kUnit + 2 * t]) = p;
+        }
+    }
+    __syncthreads();
+    sum_rows_from_lds<T, BLOCK>(prod, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);
+}
+
+// ------------------------------------------------------- stream, persistent
+// csr_stream spends its life in three dependent waits (HBM stream -> L2/MALL
+// gather -> LDS row sums) and only the first of them has HBM requests in
+// flight, so with 16-32 waves per CU the bytes in flight hover around what
+// Little's law asks for at ~6 TB/s.  Here a workgroup owns a contiguous run of
+// blocks and keeps TWO register stages: while block b is gathered, multiplied
+// and summed, the (col, val) stream of its next block is already in flight, so
+// every resident wave always has its share of HBM requests outstanding.  The
+// grid is sized to what is resident at once (persistent, grid-stride over the
+// blocks) and there is no inter-workgroup communication (nothing to deadlock
+// on).
+template <typename T, bool NT, int CAP>
+__global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int run,
+                                                          const int4 *__restrict__ desc,
+                                                          const int *__restrict__ row_ptr,
+                                                          const int *__restrict__ col,
+                                                          const T *__restrict__ val,
+                                                          const T *__restrict__ x,
+                                                          T *__restrict__ y) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * kBlock;
+    constexpr int kUnits = CAP / kUnit;
+    __shared__ T prod[CAP];
+    const int t = threadIdx.x;
+
+    // Workgroup w takes blocks w, w + G, w + 2G, ... (G = gridDim.x): at any
+    // moment the resident workgroups sit on one moving window of the matrix,
+    // which keeps DRAM pages open; giving each workgroup its own contiguous
+    // run (thousands of independent streams) measured 20 % slower.
+    const int G = gridDim.x;
+    int b = blockIdx.x;
+    if (b >= num_blocks) return;
+    (void)run;
+
+    auto issue = [&](v2i(&c)[kUnits], V2(&v)[kUnits], int first_entry) {
+        const int e_first = (first_entry & ~1) + 2 * t;
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kUnit));
+            v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+        }
+    };
+    // consume one staged block; `prefetch` issues the next block's stream right
+    // after this block's gathers so both are in flight together
+    auto step = [&](const int4 d, v2i(&c)[kUnits], V2(&v)[kUnits], auto prefetch) {
+        const int r0 = d.x, nrows = d.z;
+        const int base = d.y & ~1;
+        const int lanes = lanes_for_rows<kBlock>(nrows);
+        int seg_lo = 0, seg_hi = 0;
+        if (t / lanes < nrows) {
+            seg_lo = row_ptr[r0 + t / lanes];
+            seg_hi = row_ptr[r0 + t / lanes + 1];
+        }
+        T xv[2 * kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            xv[2 * u] = gather(x, c[u].x);
+            xv[2 * u + 1] = gather(x, c[u].y);
+        }
+        prefetch();
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            V2 p;
+            p.x = v[u].x * xv[2 * u];
+            p.y = v[u].y * xv[2 * u + 1];
+            *reinterpret_cast<V2 *>(&prod[u * kUnit + 2 * t]) = p;
+        }
+        __syncthreads();
+        sum_rows_from_lds<T, kBlock>(prod, row_ptr, y, r0, nrows, base, lanes, seg_lo - base,
+                                     seg_hi - base);
+        __syncthreads();  // prod is rewritten by the next step
+    };
+
+    // Steps that prefetch do so unconditionally (a prefetch under a branch would
+    // force the compiler to wait for ALL outstanding loads at the join, which
+    // drains the very loads that are meant to stay in flight), so the last one
+    // or two blocks of the run are peeled.
+    v2i cA[kUnits], cB[kUnits];
+    V2 vA[kUnits], vB[kUnits];
+    int left = (num_blocks - 1 - b) / G + 1;
+    int4 d = desc[b];
+    issue(cA, vA, d.y);
+    while (left >= 3) {
+        const int4 d1 = desc[b + G];
+        step(d, cA, vA, [&] { issue(cB, vB, d1.y); });
+        const int4 d2 = desc[b + 2 * G];
+        step(d1, cB, vB, [&] { issue(cA, vA, d2.y); });
+        d = d2;
+        b += 2 * G;
+        left -= 2;
+    }
+    if (left == 2) {
+        const int4 d1 = desc[b + G];
+        step(d, cA, vA, [&] { issue(cB, vB, d1.y); });
+        step(d1, cB, vB, [] {});
+    } else {
+        step(d, cA, vA, [] {});
+    }
+}
+
+// ------------------------------------------------------------ stream, row walk
+// Same blocks, different second half.  Profiling csr_stream on the nlpkkt-like
+// matrix showed HBM traffic within 7 % of the algorithmic bytes but 1.25
+// vector-L1 accesses per nonzero: with one lane per ENTRY the 64 lanes of a
+// gather hold different offsets of the same few rows, i.e. 64 far-apart x
+// addresses = 64 L1 accesses per instruction.  Here the raw (col, val) pairs
+// are staged in LDS and lane i walks ROW i (interleaved S ways when a block has
+// fewer than 128 rows): neighbouring lanes are neighbouring rows at the same
+// position, whose columns are neighbours for stencil / FEM / banded matrices,
+// so the L1 serves a gather in a few line accesses.  Row sums stay in
+// registers; the S interleaved partial sums of a row meet through LDS.  Costs
+// 12 instead of 8 bytes of LDS per entry.
+template <typename T, bool NT, bool XCD, int CAP>
+__global__ __launch_bounds__(kBlock) void csr_stream_rows(int num_blocks, int per_xcd,
+                                                          const int4 *__restrict__ desc,
+                                                          const int *__restrict__ row_ptr,
+                                                          const int *__restrict__ col,
+                                                          const T *__restrict__ val,
+                                                          const T *__restrict__ x,
+                                                          T *__restrict__ y) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnits = CAP / kStreamUnit;
+    __shared__ T lv[CAP];
+    __shared__ int lc[CAP];
+    __shared__ T part[kBlock];
+
+    const int b = XCD ? xcd_contiguous(blockIdx.x, per_xcd) : (int)blockIdx.x;
+    if (b >= num_blocks) return;
+    const int t = threadIdx.x;
+    const int4 d = desc[b];
+    const int r0 = d.x, nrows = d.z;
+    const int base = d.y & ~1;
+
+    // lane -> (row, slice): rows fastest so that neighbouring lanes are neighbouring rows
+    const int slices = nrows < kBlock ? kBlock / nrows : 1;
+    const int slice = nrows < kBlock ? t / nrows : 0;
+    int row = nrows < kBlock ? t - slice * nrows : t;
+    const bool live = slice < slices;
+    int lo = 0, hi = 0;
+    if (live && row < nrows) {
+        lo = row_ptr[r0 + row] - base;
+        hi = row_ptr[r0 + row + 1] - base;
+    }
+
+    v2i c[kUnits];
+    V2 v[kUnits];
+    const int e_first = base + 2 * t;
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kStreamUnit));
+        v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kStreamUnit));
+    }
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        *reinterpret_cast<v2i *>(&lc[u * kStreamUnit + 2 * t]) = c[u];
+        *reinterpret_cast<V2 *>(&lv[u * kStreamUnit + 2 * t]) = v[u];
+    }
+    __syncthreads();
+
+    for (int first = 0; first < nrows; first += kBlock) {  // one trip unless nrows > 256
+        if (first > 0) {
+            row = first + t;
+            lo = hi = 0;
+            if (row < nrows) {
+                lo = row_ptr[r0 + row] - base;
+                hi = row_ptr[r0 + row + 1] - base;
+            }
+        }
+        T a0 = 0, a1 = 0;
+        int k = lo + slice;
+        for (; k + 3 * slices < hi; k += 4 * slices) {
+            const int c0 = lc[k], c1 = lc[k + slices], c2 = lc[k + 2 * slices], c3 = lc[k + 3 * slices];
+            const T x0 = gather(x, c0), x1 = gather(x, c1), x2 = gather(x, c2), x3 = gather(x, c3);
+            a0 += lv[k] * x0;
+            a1 += lv[k + slices] * x1;
+            a0 += lv[k + 2 * slices] * x2;
+            a1 += lv[k + 3 * slices] * x3;
+        }
+        for (; k < hi; k += slices) a0 += lv[k] * gather(x, lc[k]);
+        const T acc = a0 + a1;
+        if (slices == 1) {
+            if (live && row < nrows) y[r0 + row] = acc;  // lanes past the last row own nothing
+        } else {
+            part[t] = acc;
+            __syncthreads();
+            if (t < nrows) {
+                T s = part[t];
+                for (int q = 1; q < slices; ++q) s += part[q * nrows + t];
+                y[r0 + t] = s;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------- long rows
+// piece = {row, first entry, end entry, slot}: one workgroup accumulates the
+// piece in registers (no staging) and stores its partial sum.
+template <typename T, bool NT>
+__global__ __launch_bounds__(kBlock) void csr_long_pieces(int count, const int4 *__restrict__ pieces,
+                                                          const int *__restrict__ col,
+                                                          const T *__restrict__ val,
+                                                          const T *__restrict__ x,
+                                                          T *__restrict__ partial) {
+    using V2 = typename vec2<T>::type;
+    __shared__ T wave_part[kBlock / 64];
+    if ((int)blockIdx.x >= count) return;
+    const int t = threadIdx.x;
+    const int4 d = pieces[blockIdx.x];
+    const int n0 = d.y, n1 = d.z;
+    T acc = 0;
+    for (int e = (n0 & ~1) + 2 * t; e < n1; e += kStreamUnit) {
+        const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(col + e));
+        const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(val + e));
+        const T p0 = e >= n0 ? v.x * gather(x, c.x) : T(0);
+        const T p1 = e + 1 < n1 ? v.y * gather(x, c.y) : T(0);
+        acc += p0;
+        acc += p1;
+    }
+    acc = group_sum<64>(acc);
+    if ((t & 63) == 0) wave_part[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) {
+        T s = wave_part[0];
+        for (int w = 1; w < kBlock / 64; ++w) s += wave_part[w];
+        partial[d.w] = s;
     }
 }
 

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void hll_thread_row(int M, const long long 
     const int m = maxnz[h];
     const long long at = hack_off[h] + (long long)i * m;
     T acc = 0;
-    for (int j = 0; j < m; ++j) acc += AS[at + j] * x[JA[at + j]];
+    for (int j = 0; j < m; ++j) acc += AS[at + j] * gather(x, JA[at + j]);
     y[r] = acc;
 }
 
@@ -62,47 +62,66 @@ __global__ __launch_bounds__(kBlock) void hll_vector(int M, const long long *__r
         const int h = r / kHack, i = r % kHack;
         const int m = maxnz[h];
         const long long at = hack_off[h] + (long long)i * m;
-        for (int j = lane; j < m; j += L) acc += AS[at + j] * x[JA[at + j]];
+        for (int j = lane; j < m; j += L) acc += AS[at + j] * gather(x, JA[at + j]);
     }
     acc = group_sum<L>(acc);
     if (lane == 0 && r < M) y[r] = acc;
 }
 
+// Stage NU units (NU * 512 slots starting at slot k0 of the range) as products:
+// straight-line, unconditional loads; only the LDS stores are bounded by count.
+// The last unit may overshoot the range by < 512 slots; JA / AS carry that much
+// zero padding behind the slab and later hacks' slots are valid anyway.
+template <typename T, bool NT, int NU>
+__device__ __forceinline__ void stage_units(T *prod, const int *__restrict__ JA,
+                                            const T *__restrict__ AS, const T *__restrict__ x,
+                                            long long from, int k0, int count) {
+    using V2 = typename vec2<T>::type;
+    const int t = threadIdx.x;
+    v2i c[NU];
+    V2 v[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int k = k0 + u * kStreamUnit + 2 * t;
+        c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(JA + from + k));
+        v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(AS + from + k));
+    }
+    T xv[2 * NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        xv[2 * u] = gather(x, c[u].x);
+        xv[2 * u + 1] = gather(x, c[u].y);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int k = k0 + u * kStreamUnit + 2 * t;
+        if (k < count) {
+            V2 p;
+            p.x = v[u].x * xv[2 * u];
+            p.y = v[u].y * xv[2 * u + 1];
+            *reinterpret_cast<V2 *>(&prod[k]) = p;
+        }
+    }
+}
+
 // Stage slots [from, from + count) of the flat slab as products in LDS.
-// `from` is even; prod[k] receives slot from + k.
+// `from` is even; prod[k] receives slot from + k.  The number of units is
+// wave-uniform, so the dispatch below is scalar branching, not predication.
 template <typename T, bool NT>
 __device__ __forceinline__ void stage_products(T *prod, const int *__restrict__ JA,
                                                const T *__restrict__ AS,
                                                const T *__restrict__ x, long long from,
                                                int count) {
-    using V2 = typename vec2<T>::type;
-    const int t = threadIdx.x;
-    constexpr int kBatch = 4;
-    for (int u0 = 0; u0 * kStreamUnit < count; u0 += kBatch) {
-        v2i c[kBatch];
-        V2 v[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int k = (u0 + u) * kStreamUnit + 2 * t;
-            if (k < count) {
-                c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(JA + from + k));
-                v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(AS + from + k));
-            } else {
-                c[u] = v2i{0, 0};
-                v[u] = V2{0, 0};
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int k = (u0 + u) * kStreamUnit + 2 * t;
-            if (k < count) {
-                V2 p;
-                p.x = v[u].x * x[c[u].x];
-                p.y = v[u].y * x[c[u].y];
-                *reinterpret_cast<V2 *>(&prod[k]) = p;
-            }
-        }
+    int units = (count + kStreamUnit - 1) / kStreamUnit;
+    int k0 = 0;
+    while (units >= 4) {
+        stage_units<T, NT, 4>(prod, JA, AS, x, from, k0, count);
+        k0 += 4 * kStreamUnit;
+        units -= 4;
     }
+    if (units == 3) stage_units<T, NT, 3>(prod, JA, AS, x, from, k0, count);
+    else if (units == 2) stage_units<T, NT, 2>(prod, JA, AS, x, from, k0, count);
+    else if (units == 1) stage_units<T, NT, 1>(prod, JA, AS, x, from, k0, count);
 }
 
 // Workgroup b owns hacks [hblk[b], hblk[b+1]).  Host packing (hll_build_blocks)
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int M, const int *__restrict__
                 const int h = h0 + q / kHack, i = q % kHack;
                 const int m = maxnz[h];
                 const int lo = (int)(hack_off[h] - base) + i * m;
-                for (int k = lo + my_lane; k < lo + m; k += lanes) acc += prod[k];
+                acc = lds_strided_sum(prod, lo, lo + m, my_lane, lanes);
             }
             acc = group_sum_rt(acc, lanes);
             if (my_lane == 0 && q < nrows) y[row_first + q] = acc;
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int M, const int *__restrict__
                 T acc = 0;
                 if (q < rows) {
                     const int lo = shift + q * m;
-                    for (int k = lo + my_lane; k < lo + m; k += lanes) acc += prod[k];
+                    acc = lds_strided_sum(prod, lo, lo + m, my_lane, lanes);
                 }
                 acc = group_sum_rt(acc, lanes);
                 if (my_lane == 0 && q < rows) y[row_first + i0 + q] = acc;
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int M, const int *__restrict__
     for (int i = 0; i < nrows; ++i) {
         const long long at = base + (long long)i * m;
         T acc = 0;
-        for (int j = t; j < m; j += kBlock) acc += AS[at + j] * x[JA[at + j]];
+        for (int j = t; j < m; j += kBlock) acc += AS[at + j] * gather(x, JA[at + j]);
         acc = group_sum<64>(acc);
         __syncthreads();
         if ((t & 63) == 0) wave_part[t >> 6] = acc;

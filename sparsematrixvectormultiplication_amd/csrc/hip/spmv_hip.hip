@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "csr_kernels.hpp"
@@ -32,6 +33,15 @@ void *g_flush_buf = nullptr;
 size_t g_flush_bytes = 0;
 ncclComm_t g_comm = nullptr;
 int g_comm_rank = 0, g_comm_size = 1;
+
+// kernel tuning knobs (spmv_hip_set_tuning); defaults are the measured best
+int g_stream_cap = 0;     // nnz staged per stream workgroup (fixed at upload); 0 = by matrix size
+int g_stream_block = 256; // threads per csr_stream workgroup
+int g_stream_nt = 1;      // non-temporal loads for col/val
+int g_stream_xcd = 0;     // XCD-contiguous workgroup order
+int g_stream_kind = 0;     // 0 = csr_stream (products), 1 = csr_stream_rows (row walk), 2 = csr_stream_pipe
+int g_pipe_wgs_per_cu = 5; // resident workgroups per CU the persistent grid is sized for
+int g_num_cus = 256;    // 1 = csr_stream_rows (row walk out of LDS), 0 = csr_stream (products)
 
 int fail(const char *fmt, ...) {
     va_list ap;
@@ -62,7 +72,8 @@ int need_device() {
     return 0;
 }
 
-constexpr int kPad = 64;  // zero entries behind col/val so 2-wide peels stay in bounds
+constexpr int kPad = 8192 + 64;  // zero entries behind col/val: the stream / LDS kernels stage
+                                   // whole units without bounds tests (>= kStreamCapMax, kHllCap)
 
 template <typename T>
 int upload_array(T **dptr, const T *host, size_t count, size_t pad) {
@@ -95,8 +106,10 @@ struct spmv_csr_dev {
     int num_blocks = 0;
     int4 *long_rows = nullptr;
     int num_long = 0;
+    int4 *pieces = nullptr;
     void *partial = nullptr;
     int num_partial = 0;
+    int stream_cap = 2048;
     // heuristics
     int lanes_per_row = 16;
     int auto_variant = SPMV_CSR_STREAM;
@@ -122,6 +135,7 @@ struct spmv_hll_dev {
 };
 
 // ------------------------------------------------------------------ device
+extern "C" int spmv_hip_set_tuning(const char *key, int value);
 extern "C" int spmv_hip_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -142,6 +156,24 @@ extern "C" int spmv_hip_init(int device) {
         g_stream = nullptr;
     }
     if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    // SPMV_TUNING="key=value,key=value": same keys as spmv_hip_set_tuning (profiling aid)
+    if (const char *env = getenv("SPMV_TUNING")) {
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos &&
+                spmv_hip_set_tuning(item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1)) != 0)
+                return -1;
+            pos = end + 1;
+        }
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        g_num_cus = cus;
     g_device = device;
     return 0;
 }
@@ -161,6 +193,32 @@ extern "C" int spmv_hip_shutdown(void) {
         g_stream = nullptr;
     }
     g_device = -1;
+    return 0;
+}
+
+extern "C" int spmv_hip_set_tuning(const char *key, int value) {
+    if (!key) return fail("set_tuning: NULL key");
+    if (!strcmp(key, "stream_cap")) {
+        if (value != 0 && value != 2048 && value != 4096 && value != 8192)
+            return fail("set_tuning: stream_cap must be 0 (auto), 2048, 4096 or 8192");
+        g_stream_cap = value;
+    } else if (!strcmp(key, "stream_block")) {
+        if (value != 256 && value != 512 && value != 1024)
+            return fail("set_tuning: stream_block must be 256, 512 or 1024");
+        g_stream_block = value;
+    } else if (!strcmp(key, "stream_nt")) {
+        g_stream_nt = value != 0;
+    } else if (!strcmp(key, "stream_xcd")) {
+        g_stream_xcd = value != 0;
+    } else if (!strcmp(key, "stream_kind")) {
+        if (value < 0 || value > 2) return fail("set_tuning: stream_kind must be 0, 1 or 2");
+        g_stream_kind = value;
+    } else if (!strcmp(key, "pipe_wgs_per_cu")) {
+        if (value < 1 || value > 8) return fail("set_tuning: pipe_wgs_per_cu must be 1..8");
+        g_pipe_wgs_per_cu = value;
+    } else {
+        return fail("set_tuning: unknown key '%s'", key);
+    }
     return 0;
 }
 
@@ -231,39 +289,36 @@ extern "C" int spmv_hip_memset(void *dptr, int byte, size_t bytes) {
 // ----------------------------------------------------------- CSR: upload
 namespace {
 
-// Cut rows [0, M) (row_ptr rebased to 0) into workgroup-sized pieces for
-// csr_stream: each descriptor is {first row | flag, first entry, partial slot, 0}
-// and a final sentinel {M, nnz, 0, 0} closes the last block.
-void csr_build_blocks(int M, const int *rp, std::vector<int4> &desc, std::vector<int4> &long_rows,
-                      int &num_partial) {
+// Cut rows [0, M) (row_ptr rebased to 0) into workgroup-sized blocks for the
+// stream kernels: desc = {first row, first entry, rows, end entry}, each block's entries
+// (counted from the even entry at or below its first) fit `cap`.  A row that
+// cannot be staged is cut into pieces {row, first entry, end entry, slot} whose
+// partial sums csr_long_finish adds up per long row {row, first slot, pieces, 0}.
+void csr_build_blocks(int M, const int *rp, int cap, std::vector<int4> &desc,
+                      std::vector<int4> &pieces, std::vector<int4> &long_rows) {
     desc.clear();
+    pieces.clear();
     long_rows.clear();
-    num_partial = 0;
     int r = 0;
     while (r < M) {
         const int n0 = rp[r];
         const int len = rp[r + 1] - n0;
         const int base = n0 & ~1;
-        if (len > kStreamCap - 1) {
-            // a row that cannot be staged: split into pieces, summed by csr_long_finish
-            const int first_slot = num_partial;
-            int pieces = 0;
-            for (int p = n0; p < rp[r + 1]; p += kLongPiece) {
-                desc.push_back(int4{r | kLongFlag, p, num_partial++, 0});
-                ++pieces;
-            }
-            long_rows.push_back(int4{r, first_slot, pieces, 0});
+        if (len > cap - 1) {
+            const int first_slot = (int)pieces.size();
+            for (int p = n0; p < rp[r + 1]; p += kLongPiece)
+                pieces.push_back(int4{r, p, std::min(p + kLongPiece, rp[r + 1]), (int)pieces.size()});
+            long_rows.push_back(int4{r, first_slot, (int)pieces.size() - first_slot, 0});
             ++r;
             continue;
         }
         int r1 = r;
-        while (r1 < M && r1 - r < kStreamRowsCap && rp[r1 + 1] - base <= kStreamCap &&
-               rp[r1 + 1] - rp[r1] <= kStreamCap - 1)
+        while (r1 < M && r1 - r < kStreamRowsCap && rp[r1 + 1] - base <= cap &&
+               rp[r1 + 1] - rp[r1] <= cap - 1)
             ++r1;
-        desc.push_back(int4{r, n0, 0, 0});
+        desc.push_back(int4{r, n0, r1 - r, rp[r1]});
         r = r1;
     }
-    desc.push_back(int4{M, M > 0 ? rp[M] : 0, 0, 0});
 }
 
 template <typename T>
@@ -274,12 +329,13 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     *out = nullptr;
     if (M < 0 || N < 0 || !row_ptr) return fail("csr_upload: bad arguments");
     if (row0 < 0 || row1 < row0 || row1 > M) return fail("csr_upload: bad row range [%d, %d) of %d", row0, row1, M);
-    if (M >= kLongFlag) return fail("csr_upload: M = %d exceeds the supported 2^30 - 1 rows", M);
     const int Ml = row1 - row0;
     const int e0 = row_ptr[row0], e1 = row_ptr[row1];
     const long long nz = (long long)e1 - e0;
     if (nz < 0) return fail("csr_upload: row_ptr is not monotone");
     if (nz > 0 && (!col_idx || !values)) return fail("csr_upload: col_idx / values are NULL");
+    if ((unsigned long long)N * sizeof(T) >= (1ull << 32))
+        return fail("csr_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
     // a column index outside [0, N) would make the kernels gather out of bounds
     for (int e = e0; e < e1; ++e)
         if ((unsigned)col_idx[e] >= (unsigned)N)
@@ -306,19 +362,23 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     }
     m->max_row = max_row;
 
-    std::vector<int4> desc, long_rows;
-    int num_partial = 0;
-    csr_build_blocks(Ml, rp.data(), desc, long_rows, num_partial);
-    m->num_blocks = (int)desc.size() - 1;
+    std::vector<int4> desc, pieces, long_rows;
+    // larger stages amortise per-workgroup latency on big matrices; small ones need
+    // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
+    m->stream_cap = g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048);
+    csr_build_blocks(Ml, rp.data(), m->stream_cap, desc, pieces, long_rows);
+    m->num_blocks = (int)desc.size();
     m->num_long = (int)long_rows.size();
-    m->num_partial = num_partial;
+    m->num_partial = (int)pieces.size();
+    const int num_partial = m->num_partial;
 
     int rc = 0;
     rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), 0);
     if (!rc) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
-    if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 0);
+    if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
     if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
+    if (!rc && num_partial) rc |= upload_array(&m->pieces, pieces.data(), pieces.size(), 0);
     if (!rc && num_partial) {
         hipError_t e = hipMalloc(&m->partial, (size_t)num_partial * sizeof(T));
         if (e != hipSuccess) rc = fail("hipMalloc(partial) failed: %s", hipGetErrorString(e));
@@ -335,7 +395,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
         return -1;
     }
     m->device_bytes = rp.size() * 4 + ((size_t)nz + kPad) * (4 + sizeof(T)) + desc.size() * 16 +
-                      long_rows.size() * 16 + (size_t)num_partial * sizeof(T) +
+                      long_rows.size() * 16 + pieces.size() * 16 + (size_t)num_partial * sizeof(T) +
                       ((size_t)N + (size_t)M) * sizeof(T);
 
     // lanes per row for the SUBWAVE kernel: about half the mean row length,
@@ -372,6 +432,7 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->val);
     (void)hipFree(m->desc);
     (void)hipFree(m->long_rows);
+    (void)hipFree(m->pieces);
     (void)hipFree(m->partial);
     (void)hipFree(m->x);
     (void)hipFree(m->y);
@@ -457,13 +518,60 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
             }
             break;
         case SPMV_CSR_STREAM: {
-            const int per_xcd = (m->num_blocks + 7) / 8;
-            hipLaunchKernelGGL((csr_stream<T, true, true>), dim3(per_xcd * 8), dim3(kBlock), 0, s,
-                               m->num_blocks, per_xcd, m->desc, m->row_ptr, m->col,
-                               (const T *)m->val, x, y, (T *)m->partial);
-            if (m->num_long)
+            if (m->num_blocks > 0) {
+                const int per_xcd = (m->num_blocks + 7) / 8;
+#define SPMV_ARGS m->desc, m->row_ptr, m->col, (const T *)m->val, x, y
+#define SPMV_LAUNCH_PROD(NT, XCD, CAP, BLOCK)                                                      \
+    hipLaunchKernelGGL((csr_stream<T, NT, XCD, CAP, BLOCK>), dim3(per_xcd * 8), dim3(BLOCK), 0, s, \
+                       m->num_blocks, per_xcd, SPMV_ARGS)
+#define SPMV_LAUNCH_WALK(NT, XCD, CAP)                                                             \
+    hipLaunchKernelGGL((csr_stream_rows<T, NT, XCD, CAP>), dim3(per_xcd * 8), dim3(kBlock), 0, s,  \
+                       m->num_blocks, per_xcd, SPMV_ARGS)
+#define SPMV_LAUNCH_FLAGS(MACRO, ...)                                     \
+    do {                                                                  \
+        if (g_stream_nt && g_stream_xcd) MACRO(true, true, __VA_ARGS__);  \
+        else if (g_stream_nt) MACRO(true, false, __VA_ARGS__);            \
+        else if (g_stream_xcd) MACRO(false, true, __VA_ARGS__);           \
+        else MACRO(false, false, __VA_ARGS__);                            \
+    } while (0)
+                const int cap = m->stream_cap, blk = g_stream_block;
+                if (g_stream_kind == 2 && cap <= 4096) {
+                    // persistent grid: what is resident at once (at least two blocks each)
+                    int wgs = std::max(1, std::min(g_num_cus * g_pipe_wgs_per_cu, (m->num_blocks + 1) / 2));
+                    const int run = (m->num_blocks + wgs - 1) / wgs;
+                    if (cap == 2048) {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
+                    } else {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
+                    }
+                } else if (g_stream_kind == 1 && cap <= 4096) {
+                    if (cap == 2048) SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_WALK, 2048);
+                    else SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_WALK, 4096);
+                } else if (cap == 2048) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 2048, 256);
+                } else if (cap == 4096 && blk == 512) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 4096, 512);
+                } else if (cap == 4096) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 4096, 256);
+                } else if (blk == 1024) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 8192, 1024);
+                } else {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 8192, 512);
+                }
+#undef SPMV_LAUNCH_FLAGS
+#undef SPMV_LAUNCH_WALK
+#undef SPMV_LAUNCH_PROD
+#undef SPMV_ARGS
+            }
+            if (m->num_long) {
+                hipLaunchKernelGGL((csr_long_pieces<T, true>), dim3(m->num_partial), dim3(kBlock), 0, s,
+                                   m->num_partial, m->pieces, m->col, (const T *)m->val, x,
+                                   (T *)m->partial);
                 hipLaunchKernelGGL((csr_long_finish<T>), dim3(m->num_long), dim3(64), 0, s,
                                    m->num_long, m->long_rows, (const T *)m->partial, y);
+            }
             break;
         }
         default:
@@ -558,6 +666,8 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
     if (!hll || !out) return fail("hll_upload: NULL argument");
     *out = nullptr;
     const int H = hll->num_blocks;
+    if ((unsigned long long)N * 8 >= (1ull << 32))
+        return fail("hll_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
     if (H != (total_rows + kHack - 1) / kHack)
         return fail("hll_upload: %d hacks do not match %d rows", H, total_rows);
 

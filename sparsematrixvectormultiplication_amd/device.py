@@ -58,6 +58,11 @@ def flush_cache(nbytes: int = 1 << 30) -> None:
     _check(nat.lib().spmv_hip_flush_cache(int(nbytes)), "spmv_hip_flush_cache")
 
 
+def set_tuning(key: str, value: int) -> None:
+    """A/B knobs of the stream kernel: stream_cap (at upload), stream_nt, stream_xcd."""
+    _check(nat.lib().spmv_hip_set_tuning(key.encode(), int(value)), "spmv_hip_set_tuning")
+
+
 class _Handle:
     _free = None
 

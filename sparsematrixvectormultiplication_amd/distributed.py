@@ -36,6 +36,18 @@ def slice_csr(row_ptr, col_idx, values, row0, row1):
     return (row_ptr[row0:row1 + 1] - row_ptr[row0]).astype(np.int32), col_idx[e0:e1], values[e0:e1]
 
 
+def local_row_ptr(row_ptr_full, row0, row1):
+    """A full-length (M + 1) row_ptr describing ONLY rows [row0, row1), with entry
+    row_ptr_full[row0] renumbered to 0.  Handing this plus the rank's own col / val
+    arrays to spmv_hip_csr_upload(..., row0, row1) uploads just that block: the C-ABI
+    reads col_idx + row_ptr[row0] = the first local entry."""
+    rp = np.ascontiguousarray(row_ptr_full, dtype=np.int32)
+    M = len(rp) - 1
+    e0 = int(rp[row0])
+    return np.concatenate([np.zeros(row0, np.int32), rp[row0:row1 + 1] - e0,
+                           np.full(M - row1, rp[row1] - e0, np.int32)]).astype(np.int32)
+
+
 def allgatherv_rows_torch(y_full, bounds, group=None):
     """In-place all-gatherv of a full-length y tensor with torch.distributed.
 
@@ -94,10 +106,7 @@ class RowPartitionedCsr:
         # upload only this rank's block: hand the C-ABI a CSR whose row_ptr is
         # the full one but whose col/val pointers are shifted so that entry
         # row_ptr[row0] is element 0 of the local arrays
-        rp = np.ascontiguousarray(row_ptr_full, dtype=np.int32)
-        e0 = int(rp[self.row0])
-        local_rp = np.concatenate([np.zeros(self.row0, np.int32), rp[self.row0:self.row1 + 1] - e0,
-                                   np.full(self.M - self.row1, rp[self.row1] - e0, np.int32)])
+        local_rp = local_row_ptr(row_ptr_full, self.row0, self.row1)
         self.dev = CsrDevice(self.M, self.N, local_rp, local_col, local_val, self.row0, self.row1)
         self.comm = comm
         self.value_bytes = 4 if np.dtype(self.dev.dtype) == np.float32 else 8

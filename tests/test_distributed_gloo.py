@@ -1,0 +1,91 @@
+"""The N > 1 path on CPU: two processes (gloo), rows split by nnz with the reference's
+greedy, each rank computes ONLY its row block (here with the oracle, there is no GPU),
+then the in-place all-gatherv of y -- the same host code bench.py runs with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _matrix(case):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _util import random_csr
+    rng = np.random.default_rng(77 + case)
+    if case == 0:      # ordinary: both ranks get rows
+        M, N = 900, 1000
+        row_ptr, col, val = random_csr(rng, M, N, 12, 40, 0.1)
+    elif case == 1:    # all nonzeros in the first rows: the second rank's block is empty
+        M, N = 300, 300
+        lens = np.zeros(M, dtype=np.int64)
+        lens[0] = 200
+        row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = np.sort(rng.choice(N, 200, replace=False)).astype(np.int32)
+        val = rng.uniform(-1, 1, 200)
+    else:              # one heavy row in the middle: very unequal row counts
+        M, N = 500, 800
+        lens = rng.integers(0, 4, M)
+        lens[250] = 700
+        row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = np.concatenate([np.sort(rng.choice(N, n, replace=False)) for n in lens]).astype(np.int32)
+        val = rng.uniform(-1, 1, row_ptr[-1])
+    x = rng.uniform(-1, 1, N)
+    return M, N, row_ptr, col, val, x
+
+
+def _worker(rank, world, port, case, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import sparsematrixvectormultiplication_amd as sp
+    from oracle.oracle import Oracle
+    from sparsematrixvectormultiplication_amd.distributed import (allgatherv_rows_torch,
+                                                                 local_row_ptr, local_rows,
+                                                                 slice_csr)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        M, N, row_ptr, col, val, x = _matrix(case)
+        oracle = Oracle()
+        bounds = sp.partition_rows(row_ptr, world)           # identical on every rank
+        r0, r1 = local_rows(bounds, rank)
+        rp_l, col_l, val_l = slice_csr(row_ptr, col, val, r0, r1)
+        # what bench.py hands to the C-ABI for this rank describes exactly this block
+        fake = local_row_ptr(row_ptr, r0, r1)
+        assert fake[r0] == 0 and fake[r1] == len(col_l) and len(fake) == M + 1
+        assert np.array_equal(fake[r0:r1 + 1], rp_l)
+        y = torch.zeros(M, dtype=torch.float64)
+        if r1 > r0:
+            y[r0:r1] = torch.from_numpy(oracle.csr_serial(rp_l, col_l, val_l, x))
+        allgatherv_rows_torch(y, bounds)                      # the exchange step
+        y_full = oracle.csr_serial(row_ptr, col, val, x)
+        assert y.numpy().tobytes() == y_full.tobytes(), "gathered y differs from the serial result"
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world
+        np.save(os.path.join(out_dir, f"ok_{case}_{rank}.npy"), bounds)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_row_partitioned_spmv_two_ranks_gloo(tmp_path, case):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    b0 = np.load(tmp_path / f"ok_{case}_0.npy")
+    b1 = np.load(tmp_path / f"ok_{case}_1.npy")
+    assert np.array_equal(b0, b1) and b0[0] == 0 and len(b0) == world + 1
+    if case == 1:
+        assert b0[1] == b0[2]  # the second rank owns no rows and the exchange still completes

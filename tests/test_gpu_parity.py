@@ -71,6 +71,54 @@ def test_csr_kernels_match_oracle_seeded(gpu, oracle, shape):
             assert_parity(dev.spmv(x, variant), y_ref, row_ptr, col, val, x, what=f"csr-{vname}")
 
 
+@pytest.mark.parametrize("mean", [1, 3, 7, 9, 12, 15, 17, 24, 40, 100, 300])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_stream_kernel_block_shapes_repeatable(gpu, oracle, mean, dtype):
+    """The stream kernels pick their lane mapping from the rows a workgroup holds
+    (> 256, 128..255, < 128 rows per 2048 / 4096 staged entries).  Sweep the mean row
+    length across all regimes, both stage sizes and both second halves, launch
+    repeatedly into a poisoned y: every row must be written, with the same value
+    each time (regression: idle lanes once stored zeros over live rows)."""
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    rng = np.random.default_rng(1000 + mean)
+    M, N = 6000, 7000
+    row_ptr, col, val = random_csr(rng, M, N, mean, 4 * mean + 4, 0.03, dtype=dtype)
+    x = rng.uniform(-1, 1, N).astype(dtype)
+    if dtype == np.float64:
+        y_ref = oracle.csr_serial(row_ptr, col, val, x)
+    else:
+        y_ref = oracle.csr_f32_accum64(row_ptr, col, val, x)
+    item = np.dtype(dtype).itemsize
+    try:
+        for cap, walk, blk in ((2048, 1, 256), (2048, 0, 256), (4096, 1, 256), (4096, 0, 256),
+                               (4096, 0, 512), (8192, 0, 512), (8192, 0, 1024), (2048, 2, 256),
+                               (4096, 2, 256)):
+            set_tuning("stream_cap", cap)
+            with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
+                dev.set_x(x)
+                if True:
+                    set_tuning("stream_kind", walk)
+                    set_tuning("stream_block", blk)
+                    first = None
+                    for rep in range(4):
+                        sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * item)  # NaN pattern
+                        dev.run(sp.CSR_STREAM)
+                        y = dev.get_y()
+                        if dtype == np.float64:
+                            assert_parity(y, y_ref, row_ptr, col, val, x,
+                                          what=f"cap={cap} kind={walk} block={blk} rep={rep}")
+                        else:
+                            err = np.max(np.abs(y.astype(np.float64) - y_ref)) / np.max(np.abs(y_ref))
+                            assert err <= FP32_NORMWISE_RTOL, f"cap={cap} kind={walk}: {err:.3e}"
+                        if first is None:
+                            first = y
+                        assert y.tobytes() == first.tobytes(), "result changed between launches"
+    finally:
+        set_tuning("stream_cap", 0)
+        set_tuning("stream_kind", 0)
+        set_tuning("stream_block", 256)
+
+
 def test_csr_long_rows_are_split_and_summed(gpu, oracle):
     """Rows longer than one workgroup's stage (2048) and longer than one piece (8192)."""
     rng = np.random.default_rng(99)
@@ -81,13 +129,20 @@ def test_csr_long_rows_are_split_and_summed(gpu, oracle):
     val = rng.uniform(-1, 1, row_ptr[-1])
     x = rng.uniform(-1, 1, N)
     y_ref = oracle.csr_serial(row_ptr, col, val, x)
-    with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
-        assert dev.info()["long_rows"] == 6
-        for vname, variant in CSR_V:
-            assert_parity(dev.spmv(x, variant), y_ref, row_ptr, col, val, x, what=f"long-{vname}")
-        # repeated launches reuse the partial-sum scratch
-        dev.run(sp.CSR_STREAM)
-        assert_parity(dev.get_y(), y_ref, row_ptr, col, val, x, what="long-rerun")
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    try:
+        for cap, expect_long in ((2048, 6), (4096, 4), (8192, 3)):
+            set_tuning("stream_cap", cap)
+            with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
+                assert dev.info()["long_rows"] == expect_long
+                for vname, variant in CSR_V:
+                    assert_parity(dev.spmv(x, variant), y_ref, row_ptr, col, val, x,
+                                  what=f"long-{vname}-cap{cap}")
+                # repeated launches reuse the partial-sum scratch
+                dev.run(sp.CSR_STREAM)
+                assert_parity(dev.get_y(), y_ref, row_ptr, col, val, x, what="long-rerun")
+    finally:
+        set_tuning("stream_cap", 0)
 
 
 def test_csr_degenerate_shapes(gpu, oracle):

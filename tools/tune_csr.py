@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""A/B the CSR kernels and the stream kernel's knobs in ONE process, interleaved rounds
+(cdna_hip_programming.md rule 24).  Usage: python tools/tune_csr.py [nlpkkt|cant] [rounds]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sparsematrixvectormultiplication_amd as sp  # noqa: E402
+from sparsematrixvectormultiplication_amd import synth  # noqa: E402
+from sparsematrixvectormultiplication_amd.device import set_tuning  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "nlpkkt"
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+sp.hip_init(0)
+M, row_ptr, col, val = synth.kkt_like() if which == "nlpkkt" else synth.fem_like()
+x = np.ones(M)
+devs = {}
+for cap in (2048, 4096, 8192):
+    set_tuning("stream_cap", cap)
+    d = sp.CsrDevice(M, M, row_ptr, col, val)
+    d.set_x(x)
+    devs[cap] = d
+info = devs[2048].info()
+algo = info["algo_bytes"]
+print(f"{which}: M={M} nnz={info['nz']} algo_bytes={algo} lanes_per_row={info['lanes_per_row']}")
+arms = [(f"prod cap={cap} block={blk} xcd={xcd}", dict(stream_kind=0, stream_block=blk, stream_nt=1, stream_xcd=xcd), cap, sp.CSR_STREAM)
+        for cap, blk in ((2048, 256), (4096, 256), (4096, 512), (8192, 512)) for xcd in (1, 0)]
+arms += [(f"walk cap=2048 xcd={xcd}", dict(stream_kind=1, stream_block=256, stream_nt=1, stream_xcd=xcd), 2048, sp.CSR_STREAM)
+         for xcd in (1, 0)]
+arms += [(f"pipe cap={cap} wgs/cu={w} nt={nt}", dict(stream_kind=2, stream_nt=nt, pipe_wgs_per_cu=w), cap, sp.CSR_STREAM)
+         for cap in (2048, 4096) for w in (2, 3, 4, 5, 6, 8) for nt in (1,)]
+arms += [("pipe cap=2048 wgs/cu=5 nt=0", dict(stream_kind=2, stream_nt=0, pipe_wgs_per_cu=5), 2048, sp.CSR_STREAM)]
+arms += [("subwave", {}, 2048, sp.CSR_SUBWAVE), ("wave_row", {}, 2048, sp.CSR_WAVE_ROW)]
+res = {a[0]: [] for a in arms}
+for r in range(rounds):
+    for name, knobs, cap, variant in arms:
+        for k, v in knobs.items():
+            set_tuning(k, v)
+        ms = devs[cap].time(variant, warmup=2, iters=20, zero_y=False)
+        res[name].append(ms)
+t0 = __import__("time").perf_counter(); sp.flush_cache(1 << 30); sp.flush_cache(1 << 30)
+t1 = __import__("time").perf_counter(); sp.flush_cache(1 << 30); t2 = __import__("time").perf_counter()
+print(f"read+write sweep of 1 GiB: {2 * (1 << 30) / (t2 - t1) / 1e9:.0f} GB/s (host-timed, incl. launch+sync)")
+print(f"{'arm':34s} {'mean us':>9s} {'min us':>9s} {'GB/s(mean)':>11s} {'% of 8TB/s':>10s}")
+for name, *_ in arms:
+    ms = np.concatenate(res[name])
+    print(f"{name:34s} {ms.mean()*1e3:9.1f} {ms.min()*1e3:9.1f} {algo/ms.mean()/1e6:11.1f} "
+          f"{algo/ms.mean()/1e6/80:10.1f}")
