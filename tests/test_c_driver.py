@@ -1,0 +1,44 @@
+"""The C driver (csrc/driver/spmv_bench.c): a plain-C host over the C-ABI, reference protocol."""
+import csv
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, GOLDEN_CASES, ROOT
+
+DRIVER = os.path.join(ROOT, "sparsematrixvectormultiplication_amd", "spmv_bench")
+ORACLE = os.path.join(ROOT, "oracle", "liboracle_spmv.so")
+
+
+@pytest.mark.gpu
+def test_c_driver_runs_reference_protocol_on_golden_matrices(tmp_path, gpu):
+    out = tmp_path / "result"
+    proc = subprocess.run([DRIVER, "--oracle", ORACLE, "--out", str(out), "--iters", "10", GOLDEN],
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    rows = list(csv.DictReader(open(out / "spmv_results_hip.csv")))
+    assert sorted(r["matrix_name"] for r in rows) == sorted(n + ".mtx" for n in GOLDEN_CASES)
+    # the reference's GPU CSV schema (cuda_src/utility.cu:115-123), unchanged
+    assert list(rows[0])[:8] == ["matrix_name", "rows", "cols", "nonzeros", "time_serial",
+                                 "time_serial_hll", "time_row_csr", "time_warp_csr"]
+    for r in rows:
+        for key in ("relative_error_row_csr", "relative_error_warp_csr", "relative_error_warp_shared_csr",
+                    "relative_error_row_hll", "relative_error_warp_hll", "relative_error_warp_shared_hll"):
+            assert float(r[key]) < 1e-10, (r["matrix_name"], key, r[key])
+        if int(r["nonzeros"]) > 0:
+            assert float(r["time_warp_csr"]) > 0 and float(r["flops_warp_csr"]) > 0
+    roof = list(csv.DictReader(open(out / "spmv_results_hip_roofline.csv")))
+    assert len(roof) == len(rows) and all(float(r["rel_err_stream_csr"]) < 1e-10 for r in roof)
+    # running again appends, never wipes (the reference deletes the result directory)
+    subprocess.run([DRIVER, "--out", str(out), "--iters", "6", os.path.join(GOLDEN, "general_matrix.mtx")],
+                   check=True, capture_output=True, timeout=120)
+    assert len(list(csv.DictReader(open(out / "spmv_results_hip.csv")))) == len(rows) + 1
+
+
+def test_c_driver_fails_loudly_without_a_gpu(tmp_path):
+    import sparsematrixvectormultiplication_amd as sp
+    if sp.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    proc = subprocess.run([DRIVER, "--out", str(tmp_path / "r"), GOLDEN], capture_output=True, text=True)
+    assert proc.returncode == 1 and "no usable HIP device" in proc.stderr
