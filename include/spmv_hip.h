@@ -90,10 +90,10 @@ int spmv_hip_device_name(char *buf, size_t len, int *compute_units, long long *h
 int spmv_hip_flush_cache(size_t bytes);
 /* Kernel tuning knobs, for A/B measurements: "stream_cap" (2048 | 4096 | 8192 nnz staged
  * per csr_stream workgroup; read at upload), "stream_nt" (0/1 non-temporal
- * col/val loads), "stream_xcd" (0/1 XCD-contiguous workgroup order), "stream_block" (256 | 512 | 1024
+ * col/val loads), "stream_xcd" (blocks per XCD run: 0 dispatch order, -1 one contiguous eighth per XCD), "stream_block" (256 | 512 | 1024
  * threads), "stream_kind" (0 = one workgroup per block, products summed out of
  * LDS; 1 = rows walked out of LDS by neighbouring lanes; 2 = persistent,
- * double-buffered product kernel), "pipe_wgs_per_cu" (grid of kind 2). */
+ * double-buffered product kernel; 3 = persistent row walk), "pipe_wgs_per_cu" (grid of kind 2). */
 int spmv_hip_set_tuning(const char *key, int value);
 
 /* raw device buffers, for callers that keep x / y on the device themselves */

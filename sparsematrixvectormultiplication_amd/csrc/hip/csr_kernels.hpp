@@ -19,6 +19,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wave_ops.hpp"
 
 namespace spmv {
@@ -60,6 +62,18 @@ __device__ __forceinline__ T gather(const T *__restrict__ x, int c) {
 // instead of all eight XCDs caching the same window.
 __device__ __forceinline__ int xcd_contiguous(int bid, int per_xcd) {
     return (bid & 7) * per_xcd + (bid >> 3);
+}
+
+// Chunked variant: XCD x (= id & 7, ids are dealt round-robin over the XCDs) takes
+// runs of `chunk` consecutive blocks, the eight XCDs sit on eight neighbouring
+// runs.  chunk = 0 keeps dispatch order (neighbouring blocks on different XCDs:
+// every L2 sees the x window of ALL resident blocks); a chunk of a few hundred
+// blocks gives each L2 only its own blocks' x window while the chip as a whole
+// still streams through one moving window of the matrix (DRAM page locality).
+__device__ __forceinline__ int xcd_chunked(int id, int chunk) {
+    if (chunk <= 0) return id;
+    const int xcd = id & 7, seq = id >> 3;
+    return ((seq / chunk) * 8 + xcd) * chunk + seq % chunk;
 }
 
 // ---------------------------------------------------------------- thread/row
@@ -145,7 +159,7 @@ __device__ __forceinline__ T lds_strided_sum(const T *prod, int lo, int hi, int 
 // every row of the block its own lane group in one pass
 template <int BLOCK>
 __device__ __forceinline__ int lanes_for_rows(int nrows) {
-    if (nrows > BLOCK / 2) return 1;
+    if (nrows > BLOCK / 2 || nrows <= 0) return 1;
     const int l = 1 << (31 - __clz(BLOCK / nrows));
     return l > 64 ? 64 : l;
 }
@@ -174,8 +188,8 @@ __device__ __forceinline__ void sum_rows_from_lds(const T *prod, const int *__re
 }
 
 // One workgroup per block: stage products, sum rows.
-template <typename T, bool NT, bool XCD, int CAP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int per_xcd,
+template <typename T, bool NT, int CAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chunk,
                                                     const int4 *__restrict__ desc,
                                                     const int *__restrict__ row_ptr,
                                                     const int *__restrict__ col,
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int per_xcd,
     constexpr int kUnits = CAP / kUnit;
     __shared__ T prod[CAP];
 
-    const int b = XCD ? xcd_contiguous(blockIdx.x, per_xcd) : (int)blockIdx.x;
+    const int b = xcd_chunked(blockIdx.x, xcd_chunk);
     if (b >= num_blocks) return;  // whole workgroup leaves together
     const int t = threadIdx.x;
     const int4 d = desc[b];
@@ -241,6 +255,73 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int per_xcd,
     sum_rows_from_lds<T, BLOCK>(prod, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);
 }
 
+// ------------------------------------------------------------------- probe
+// Ablation of csr_stream (measurement aid, results are NOT y = A x): what does each
+// phase cost?  MODE bit 0: gather x (else x = 1), bit 2: gather from x[c & 1023], bit 1: LDS stage + row sums (else
+// lanes keep their products and one value per lane-pair is stored).
+template <typename T, bool NT, int CAP, int MODE>
+__global__ __launch_bounds__(kBlock) void csr_probe(int num_blocks, int xcd_chunk,
+                                                    const int4 *__restrict__ desc,
+                                                    const int *__restrict__ row_ptr,
+                                                    const int *__restrict__ col,
+                                                    const T *__restrict__ val,
+                                                    const T *__restrict__ x, T *__restrict__ y) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnits = CAP / kStreamUnit;
+    __shared__ T prod[CAP];
+    const int b = xcd_chunked(blockIdx.x, xcd_chunk);
+    if (b >= num_blocks) return;
+    const int t = threadIdx.x;
+    const int4 d = desc[b];
+    const int r0 = d.x, nrows = d.z;
+    const int base = d.y & ~1;
+    const int lanes = lanes_for_rows<kBlock>(nrows);
+    int seg_lo = 0, seg_hi = 0;
+    if ((MODE & 2) && t / lanes < nrows) {
+        seg_lo = row_ptr[r0 + t / lanes];
+        seg_hi = row_ptr[r0 + t / lanes + 1];
+    }
+    v2i c[kUnits];
+    V2 v[kUnits];
+    const int e_first = base + 2 * t;
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kStreamUnit));
+        v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kStreamUnit));
+    }
+    T xv[2 * kUnits];
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        if (MODE & 4) {  // same instructions, indices folded into an 8 KiB (L1-resident) table
+            xv[2 * u] = gather(x, c[u].x & 1023);
+            xv[2 * u + 1] = gather(x, c[u].y & 1023);
+        } else if (MODE & 1) {
+            xv[2 * u] = gather(x, c[u].x);
+            xv[2 * u + 1] = gather(x, c[u].y);
+        } else {
+            xv[2 * u] = T(c[u].x & 1);  // keeps the column loads alive
+            xv[2 * u + 1] = T(c[u].y & 1);
+        }
+    }
+    if (MODE & 2) {
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            V2 p;
+            p.x = v[u].x * xv[2 * u];
+            p.y = v[u].y * xv[2 * u + 1];
+            *reinterpret_cast<V2 *>(&prod[u * kStreamUnit + 2 * t]) = p;
+        }
+        __syncthreads();
+        sum_rows_from_lds<T, kBlock>(prod, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);
+    } else {
+        T acc = 0;
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) acc += v[u].x * xv[2 * u] + v[u].y * xv[2 * u + 1];
+        acc = group_sum<64>(acc);  // every lane's loads feed a stored value
+        if ((t & 63) == 0 && (t >> 6) < nrows) y[r0 + (t >> 6)] = acc;
+    }
+}
+
 // ------------------------------------------------------- stream, persistent
 // csr_stream spends its life in three dependent waits (HBM stream -> L2/MALL
 // gather -> LDS row sums) and only the first of them has HBM requests in
@@ -253,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int per_xcd,
 // blocks) and there is no inter-workgroup communication (nothing to deadlock
 // on).
 template <typename T, bool NT, int CAP>
-__global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int run,
+__global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int xcd_chunk,
                                                           const int4 *__restrict__ desc,
                                                           const int *__restrict__ row_ptr,
                                                           const int *__restrict__ col,
@@ -270,10 +351,16 @@ __global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int ru
     // moment the resident workgroups sit on one moving window of the matrix,
     // which keeps DRAM pages open; giving each workgroup its own contiguous
     // run (thousands of independent streams) measured 20 % slower.
+    // (with xcd_chunk > 0 the linear index is remapped so that an XCD's
+    // workgroups share runs of blocks, see xcd_chunked)
     const int G = gridDim.x;
     int b = blockIdx.x;
-    if (b >= num_blocks) return;
-    (void)run;
+    const int total = xcd_chunk > 0 ? (num_blocks + 8 * xcd_chunk - 1) / (8 * xcd_chunk) * (8 * xcd_chunk) : num_blocks;
+    if (b >= total) return;
+    auto block_of = [&](int linear) {  // descriptor of a linear index; past the end: an empty block
+        const int real = xcd_chunked(linear, xcd_chunk);
+        return real < num_blocks ? desc[real] : int4{0, 0, 0, 0};
+    };
 
     auto issue = [&](v2i(&c)[kUnits], V2(&v)[kUnits], int first_entry) {
         const int e_first = (first_entry & ~1) + 2 * t;
@@ -320,20 +407,20 @@ __global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int ru
     // or two blocks of the run are peeled.
     v2i cA[kUnits], cB[kUnits];
     V2 vA[kUnits], vB[kUnits];
-    int left = (num_blocks - 1 - b) / G + 1;
-    int4 d = desc[b];
+    int left = (total - 1 - b) / G + 1;
+    int4 d = block_of(b);
     issue(cA, vA, d.y);
     while (left >= 3) {
-        const int4 d1 = desc[b + G];
+        const int4 d1 = block_of(b + G);
         step(d, cA, vA, [&] { issue(cB, vB, d1.y); });
-        const int4 d2 = desc[b + 2 * G];
+        const int4 d2 = block_of(b + 2 * G);
         step(d1, cB, vB, [&] { issue(cA, vA, d2.y); });
         d = d2;
         b += 2 * G;
         left -= 2;
     }
     if (left == 2) {
-        const int4 d1 = desc[b + G];
+        const int4 d1 = block_of(b + G);
         step(d, cA, vA, [&] { issue(cB, vB, d1.y); });
         step(d1, cB, vB, [] {});
     } else {
@@ -342,19 +429,38 @@ __global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int ru
 }
 
 // ------------------------------------------------------------ stream, row walk
-// Same blocks, different second half.  Profiling csr_stream on the nlpkkt-like
-// matrix showed HBM traffic within 7 % of the algorithmic bytes but 1.25
-// vector-L1 accesses per nonzero: with one lane per ENTRY the 64 lanes of a
-// gather hold different offsets of the same few rows, i.e. 64 far-apart x
-// addresses = 64 L1 accesses per instruction.  Here the raw (col, val) pairs
-// are staged in LDS and lane i walks ROW i (interleaved S ways when a block has
-// fewer than 128 rows): neighbouring lanes are neighbouring rows at the same
-// position, whose columns are neighbours for stencil / FEM / banded matrices,
-// so the L1 serves a gather in a few line accesses.  Row sums stay in
-// registers; the S interleaved partial sums of a row meet through LDS.  Costs
-// 12 instead of 8 bytes of LDS per entry.
-template <typename T, bool NT, bool XCD, int CAP>
-__global__ __launch_bounds__(kBlock) void csr_stream_rows(int num_blocks, int per_xcd,
+// Same blocks, different second half, and the default for fp64.
+//
+// Why: on gfx950 an 8-byte gather costs per DISTINCT CACHE LINE of the wave
+// instruction, not per lane (tools/ubench_gather.hip: 64 lanes on 64 lines that
+// hit L2 = 145 cycles, on 28 clusters = 60, 8 lanes per line = 36, contiguous =
+// 17), and the coalesced (col, val) stream itself already takes ~0.4 cycles
+// per nonzero of the same address/L1 pipeline.  At 70 % of the HBM roofline a CU
+// has ~1.4 cycles per nonzero in total, so gathers must average well under one
+// cycle per lane.  With one lane per ENTRY (csr_stream) the 64 lanes of a
+// gather hold different offsets of the same few rows: far-apart addresses,
+// ~1 cycle per lane, and the vector-memory pipeline (TA_BUSY 82-92 %), not HBM,
+// sets the pace.  Here the raw (col, val) pairs are staged in LDS and lane i
+// walks ROW i (S lanes interleaved per row when a block has fewer than 128
+// rows): neighbouring lanes are neighbouring rows at the same position, whose
+// columns are neighbours for stencil / FEM / banded matrices, so a gather
+// touches a handful of lines.  For unstructured matrices it costs what
+// csr_stream's gather costs.
+//
+// Structure: persistent, grid-stride over the blocks (DRAM page locality: all
+// resident workgroups sit on one moving window of the matrix).  Per block:
+// registers -> LDS, barrier, issue the NEXT block's stream into the freed
+// registers, walk the rows (gathers in batches of 8/4/2/1 so several are in
+// flight per lane), merge the S partial sums of each row through LDS, store y,
+// barrier.  The HBM stream of block b+G is in flight during the walk of block b.
+//
+// LDS index k -> k + (k >> 5): one pad slot per 32 entries, so that rows whose
+// length shares a factor with the bank count (28-entry rows: 4-way conflicts
+// unpadded) spread over the banks.
+__device__ __forceinline__ int lds_pad(int k) { return k + (k >> 5); }
+
+template <typename T, bool NT, int CAP, bool PERSIST>
+__global__ __launch_bounds__(kBlock) void csr_stream_walk(int num_blocks, int xcd_chunk,
                                                           const int4 *__restrict__ desc,
                                                           const int *__restrict__ row_ptr,
                                                           const int *__restrict__ col,
@@ -363,76 +469,140 @@ __global__ __launch_bounds__(kBlock) void csr_stream_rows(int num_blocks, int pe
                                                           T *__restrict__ y) {
     using V2 = typename vec2<T>::type;
     constexpr int kUnits = CAP / kStreamUnit;
-    __shared__ T lv[CAP];
-    __shared__ int lc[CAP];
+    constexpr int kLds = CAP + CAP / 32 + 2;
+    __shared__ T lv[kLds];
+    __shared__ int lc[kLds];
     __shared__ T part[kBlock];
-
-    const int b = XCD ? xcd_contiguous(blockIdx.x, per_xcd) : (int)blockIdx.x;
-    if (b >= num_blocks) return;
     const int t = threadIdx.x;
-    const int4 d = desc[b];
-    const int r0 = d.x, nrows = d.z;
-    const int base = d.y & ~1;
-
-    // lane -> (row, slice): rows fastest so that neighbouring lanes are neighbouring rows
-    const int slices = nrows < kBlock ? kBlock / nrows : 1;
-    const int slice = nrows < kBlock ? t / nrows : 0;
-    int row = nrows < kBlock ? t - slice * nrows : t;
-    const bool live = slice < slices;
-    int lo = 0, hi = 0;
-    if (live && row < nrows) {
-        lo = row_ptr[r0 + row] - base;
-        hi = row_ptr[r0 + row + 1] - base;
-    }
+    const int G = gridDim.x;
+    int b = blockIdx.x;
+    const int total = xcd_chunk > 0 ? (num_blocks + 8 * xcd_chunk - 1) / (8 * xcd_chunk) * (8 * xcd_chunk) : num_blocks;
+    if (b >= total) return;
+    auto block_of = [&](int linear) {
+        const int real = xcd_chunked(linear, xcd_chunk);
+        return real < num_blocks ? desc[real] : int4{0, 0, 0, 0};
+    };
 
     v2i c[kUnits];
     V2 v[kUnits];
-    const int e_first = base + 2 * t;
+    auto issue = [&](int first_entry) {
+        const int e_first = (first_entry & ~1) + 2 * t;
 #pragma unroll
-    for (int u = 0; u < kUnits; ++u) {
-        c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kStreamUnit));
-        v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kStreamUnit));
-    }
-#pragma unroll
-    for (int u = 0; u < kUnits; ++u) {
-        *reinterpret_cast<v2i *>(&lc[u * kStreamUnit + 2 * t]) = c[u];
-        *reinterpret_cast<V2 *>(&lv[u * kStreamUnit + 2 * t]) = v[u];
-    }
-    __syncthreads();
-
-    for (int first = 0; first < nrows; first += kBlock) {  // one trip unless nrows > 256
-        if (first > 0) {
-            row = first + t;
-            lo = hi = 0;
-            if (row < nrows) {
-                lo = row_ptr[r0 + row] - base;
-                hi = row_ptr[r0 + row + 1] - base;
-            }
+        for (int u = 0; u < kUnits; ++u) {
+            c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kStreamUnit));
+            v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kStreamUnit));
         }
+    };
+    // N gathers in flight, then N fused multiply-adds
+    auto batch = [&](auto n_tag, int k, int step, T &a0, T &a1) {
+        constexpr int N = decltype(n_tag)::value;
+        int cc[N];
+        T xx[N], vv[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) cc[j] = lc[lds_pad(k + j * step)];
+#pragma unroll
+        for (int j = 0; j < N; ++j) xx[j] = gather(x, cc[j]);
+#pragma unroll
+        for (int j = 0; j < N; ++j) vv[j] = lv[lds_pad(k + j * step)];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j & 1) a1 += vv[j] * xx[j];
+            else a0 += vv[j] * xx[j];
+        }
+    };
+    auto walk = [&](int lo, int hi, int first, int step) -> T {
         T a0 = 0, a1 = 0;
-        int k = lo + slice;
-        for (; k + 3 * slices < hi; k += 4 * slices) {
-            const int c0 = lc[k], c1 = lc[k + slices], c2 = lc[k + 2 * slices], c3 = lc[k + 3 * slices];
-            const T x0 = gather(x, c0), x1 = gather(x, c1), x2 = gather(x, c2), x3 = gather(x, c3);
-            a0 += lv[k] * x0;
-            a1 += lv[k + slices] * x1;
-            a0 += lv[k + 2 * slices] * x2;
-            a1 += lv[k + 3 * slices] * x3;
+        int k = lo + first;
+        int rem = k < hi ? (hi - k + step - 1) / step : 0;  // entries this lane owns
+        while (rem >= 8) {
+            batch(std::integral_constant<int, 8>{}, k, step, a0, a1);
+            k += 8 * step;
+            rem -= 8;
         }
-        for (; k < hi; k += slices) a0 += lv[k] * gather(x, lc[k]);
-        const T acc = a0 + a1;
-        if (slices == 1) {
-            if (live && row < nrows) y[r0 + row] = acc;  // lanes past the last row own nothing
-        } else {
-            part[t] = acc;
-            __syncthreads();
-            if (t < nrows) {
-                T s = part[t];
-                for (int q = 1; q < slices; ++q) s += part[q * nrows + t];
-                y[r0 + t] = s;
+        if (rem & 4) {
+            batch(std::integral_constant<int, 4>{}, k, step, a0, a1);
+            k += 4 * step;
+        }
+        if (rem & 2) {
+            batch(std::integral_constant<int, 2>{}, k, step, a0, a1);
+            k += 2 * step;
+        }
+        if (rem & 1) batch(std::integral_constant<int, 1>{}, k, step, a0, a1);
+        return a0 + a1;
+    };
+    // one block: its stream is in c/v on entry; `prefetch` refills c/v for a later block
+    auto step_block = [&](const int4 d, auto prefetch) {
+        const int r0 = d.x, nrows = d.z;
+        const int base = d.y & ~1;
+        // lane -> (row, slice), rows fastest so that neighbouring lanes are neighbouring rows
+        const int nr = nrows > 0 ? nrows : 1;  // a dummy block past the end has no rows
+        const int slices = nrows < kBlock ? kBlock / nr : 1;
+        const int slice = nrows < kBlock ? t / nr : 0;
+        int row = nrows < kBlock ? t - slice * nrows : t;
+        const bool live = slice < slices;
+        int lo = 0, hi = 0;
+        if (live && row < nrows) {
+            lo = row_ptr[r0 + row];
+            hi = row_ptr[r0 + row + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            const int k = lds_pad(u * kStreamUnit + 2 * t);  // a pair never straddles a pad slot
+            lc[k] = c[u].x;
+            lc[k + 1] = c[u].y;
+            lv[k] = v[u].x;
+            lv[k + 1] = v[u].y;
+        }
+        __syncthreads();
+        prefetch();
+        lo -= base;
+        hi -= base;
+        for (int first = 0; first < nrows; first += kBlock) {  // one trip unless nrows > 256
+            if (first > 0) {
+                row = first + t;
+                lo = hi = 0;
+                if (row < nrows) {
+                    lo = row_ptr[r0 + row] - base;
+                    hi = row_ptr[r0 + row + 1] - base;
+                }
+            }
+            const T acc = walk(lo, hi, slice, slices);
+            if (slices == 1) {
+                if (live && row < nrows) y[r0 + row] = acc;  // lanes past the last row own nothing
+            } else {
+                part[t] = acc;
+                __syncthreads();
+                if (t < nrows) {
+                    T s = part[t];
+                    for (int q = 1; q < slices; ++q) s += part[q * nrows + t];
+                    y[r0 + t] = s;
+                }
             }
         }
+        __syncthreads();  // lc / lv / part are rewritten by the next block
+    };
+
+    if constexpr (!PERSIST) {
+        // one block per workgroup: overlap comes from the other workgroups on the CU.
+        // (Loads return in order per wave, so gathers issued behind a prefetched HBM
+        // stream would wait for it; the persistent form only pays off when the walk
+        // is short.)
+        const int4 d = block_of(b);
+        issue(d.y);
+        step_block(d, [] {});
+        return;
     }
+    int left = (total - 1 - b) / G + 1;
+    int4 d = block_of(b);
+    issue(d.y);
+    while (left >= 2) {  // prefetching steps are unconditional (see csr_stream_pipe)
+        const int4 dn = block_of(b + G);
+        step_block(d, [&] { issue(dn.y); });
+        d = dn;
+        b += G;
+        --left;
+    }
+    step_block(d, [] {});
 }
 
 // ----------------------------------------------------------------- long rows

@@ -38,7 +38,7 @@ int g_comm_rank = 0, g_comm_size = 1;
 int g_stream_cap = 0;     // nnz staged per stream workgroup (fixed at upload); 0 = by matrix size
 int g_stream_block = 256; // threads per csr_stream workgroup
 int g_stream_nt = 1;      // non-temporal loads for col/val
-int g_stream_xcd = 0;     // XCD-contiguous workgroup order
+int g_stream_xcd = 0;     // blocks per XCD run (xcd_chunked); 0 = dispatch order, -1 = one contiguous eighth per XCD
 int g_stream_kind = 0;     // 0 = csr_stream (products), 1 = csr_stream_rows (row walk), 2 = csr_stream_pipe
 int g_pipe_wgs_per_cu = 5; // resident workgroups per CU the persistent grid is sized for
 int g_num_cus = 256;    // 1 = csr_stream_rows (row walk out of LDS), 0 = csr_stream (products)
@@ -209,9 +209,11 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "stream_nt")) {
         g_stream_nt = value != 0;
     } else if (!strcmp(key, "stream_xcd")) {
-        g_stream_xcd = value != 0;
+        if (value < -1) return fail("set_tuning: stream_xcd must be -1, 0 or a positive run length");
+        g_stream_xcd = value;
     } else if (!strcmp(key, "stream_kind")) {
-        if (value < 0 || value > 2) return fail("set_tuning: stream_kind must be 0, 1 or 2");
+        if ((value < 0 || value > 3) && (value < 10 || value > 17))
+            return fail("set_tuning: stream_kind must be 0..3 (or 10..13 for the ablation probes)");
         g_stream_kind = value;
     } else if (!strcmp(key, "pipe_wgs_per_cu")) {
         if (value < 1 || value > 8) return fail("set_tuning: pipe_wgs_per_cu must be 1..8");
@@ -521,34 +523,50 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
             if (m->num_blocks > 0) {
                 const int per_xcd = (m->num_blocks + 7) / 8;
 #define SPMV_ARGS m->desc, m->row_ptr, m->col, (const T *)m->val, x, y
-#define SPMV_LAUNCH_PROD(NT, XCD, CAP, BLOCK)                                                      \
-    hipLaunchKernelGGL((csr_stream<T, NT, XCD, CAP, BLOCK>), dim3(per_xcd * 8), dim3(BLOCK), 0, s, \
-                       m->num_blocks, per_xcd, SPMV_ARGS)
-#define SPMV_LAUNCH_WALK(NT, XCD, CAP)                                                             \
-    hipLaunchKernelGGL((csr_stream_rows<T, NT, XCD, CAP>), dim3(per_xcd * 8), dim3(kBlock), 0, s,  \
-                       m->num_blocks, per_xcd, SPMV_ARGS)
-#define SPMV_LAUNCH_FLAGS(MACRO, ...)                                     \
-    do {                                                                  \
-        if (g_stream_nt && g_stream_xcd) MACRO(true, true, __VA_ARGS__);  \
-        else if (g_stream_nt) MACRO(true, false, __VA_ARGS__);            \
-        else if (g_stream_xcd) MACRO(false, true, __VA_ARGS__);           \
-        else MACRO(false, false, __VA_ARGS__);                            \
+#define SPMV_LAUNCH_PROD(NT, CAP, BLOCK)                                                          \
+    hipLaunchKernelGGL((csr_stream<T, NT, CAP, BLOCK>), dim3(grid_blocks), dim3(BLOCK), 0, s,      \
+                       m->num_blocks, chunk, SPMV_ARGS)
+#define SPMV_LAUNCH_FLAGS(MACRO, ...)              \
+    do {                                           \
+        if (g_stream_nt) MACRO(true, __VA_ARGS__); \
+        else MACRO(false, __VA_ARGS__);            \
     } while (0)
+                // blocks per XCD run; a dummy empty block is harmless for the persistent kernels
+                const int chunk = g_stream_xcd < 0 ? per_xcd : g_stream_xcd;
+                const int grid_blocks = chunk > 0 ? (m->num_blocks + 8 * chunk - 1) / (8 * chunk) * (8 * chunk)
+                                                  : m->num_blocks;
                 const int cap = m->stream_cap, blk = g_stream_block;
-                if (g_stream_kind == 2 && cap <= 4096) {
+                if (g_stream_kind >= 10 && g_stream_kind <= 17 && (cap == 2048 || cap == 4096)) {
+                    // ablation probes (measurement only; y is not A x)
+#define SPMV_PROBE(CAP, MODE) hipLaunchKernelGGL((csr_probe<T, true, CAP, MODE>), dim3(grid_blocks), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS)
+                    const int mode = g_stream_kind - 10;
+                    if (cap == 2048) { if (mode == 0) SPMV_PROBE(2048, 0); else if (mode == 1) SPMV_PROBE(2048, 1); else if (mode == 2) SPMV_PROBE(2048, 2); else if (mode == 3) SPMV_PROBE(2048, 3); else if (mode == 5) SPMV_PROBE(2048, 5); else SPMV_PROBE(2048, 7); }
+                    else { if (mode == 0) SPMV_PROBE(4096, 0); else if (mode == 1) SPMV_PROBE(4096, 1); else if (mode == 2) SPMV_PROBE(4096, 2); else if (mode == 3) SPMV_PROBE(4096, 3); else if (mode == 5) SPMV_PROBE(4096, 5); else SPMV_PROBE(4096, 7); }
+#undef SPMV_PROBE
+                } else if (g_stream_kind == 2 && cap <= 4096) {
                     // persistent grid: what is resident at once (at least two blocks each)
-                    int wgs = std::max(1, std::min(g_num_cus * g_pipe_wgs_per_cu, (m->num_blocks + 1) / 2));
-                    const int run = (m->num_blocks + wgs - 1) / wgs;
+                    int wgs = std::max(8, std::min(g_num_cus * g_pipe_wgs_per_cu, (m->num_blocks + 1) / 2) / 8 * 8);
                     if (cap == 2048) {
-                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
-                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
                     } else {
-                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
-                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, run, SPMV_ARGS);
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
                     }
-                } else if (g_stream_kind == 1 && cap <= 4096) {
-                    if (cap == 2048) SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_WALK, 2048);
-                    else SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_WALK, 4096);
+                } else if ((g_stream_kind == 1 || g_stream_kind == 3) && cap <= 4096) {
+                    // kind 1: one block per workgroup; kind 3: persistent grid-stride
+                    const bool persist = g_stream_kind == 3;
+                    const int wgs = persist ? std::max(8, std::min(g_num_cus * g_pipe_wgs_per_cu, m->num_blocks) / 8 * 8)
+                                            : grid_blocks;
+#define SPMV_WALK(NT, CAP, P) hipLaunchKernelGGL((csr_stream_walk<T, NT, CAP, P>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS)
+                    if (cap == 2048) {
+                        if (persist) { if (g_stream_nt) SPMV_WALK(true, 2048, true); else SPMV_WALK(false, 2048, true); }
+                        else { if (g_stream_nt) SPMV_WALK(true, 2048, false); else SPMV_WALK(false, 2048, false); }
+                    } else {
+                        if (persist) { if (g_stream_nt) SPMV_WALK(true, 4096, true); else SPMV_WALK(false, 4096, true); }
+                        else { if (g_stream_nt) SPMV_WALK(true, 4096, false); else SPMV_WALK(false, 4096, false); }
+                    }
+#undef SPMV_WALK
                 } else if (cap == 2048) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 2048, 256);
                 } else if (cap == 4096 && blk == 512) {
@@ -561,7 +579,6 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 8192, 512);
                 }
 #undef SPMV_LAUNCH_FLAGS
-#undef SPMV_LAUNCH_WALK
 #undef SPMV_LAUNCH_PROD
 #undef SPMV_ARGS
             }

@@ -92,7 +92,7 @@ def test_stream_kernel_block_shapes_repeatable(gpu, oracle, mean, dtype):
     try:
         for cap, walk, blk in ((2048, 1, 256), (2048, 0, 256), (4096, 1, 256), (4096, 0, 256),
                                (4096, 0, 512), (8192, 0, 512), (8192, 0, 1024), (2048, 2, 256),
-                               (4096, 2, 256)):
+                               (4096, 2, 256), (2048, 3, 256), (4096, 3, 256)):
             set_tuning("stream_cap", cap)
             with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
                 dev.set_x(x)
