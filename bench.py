@@ -255,6 +255,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
+    # one rank per GPU; if the launcher narrowed the visible devices per rank, ordinals restart at 0
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     sp.hip_init(local_rank)
     dev_name, cus, _ = sp.device_name()
@@ -294,15 +296,26 @@ def main():
     if world > 1:
         exchange = args.exchange
         if exchange == "rccl":
+            ok = 1
             try:
                 def share(ident):
                     box = [ident]
                     dist.broadcast_object_list(box, src=0)
                     return box[0]
                 comm = NativeComm(rank, world, share)
+                dev.step_time(bounds, variant, 0, 1)      # first exchange: fail here, not in the timed region
             except Exception as exc:  # both transports are RCCL; fall back to torch's
-                log(f"[rank {rank}] native RCCL communicator unavailable ({exc}); using torch.distributed")
+                log(f"[rank {rank}] native RCCL communicator unavailable ({exc})")
+                ok = 0
+            # every rank must take the same transport
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                    comm = None
                 exchange = "torch"
+                log(f"[rank {rank}] using torch.distributed for the all-gatherv")
         if exchange == "torch":
             y_t = torch.zeros(M, dtype=torch.float32 if vb == 4 else torch.float64, device="cuda")
             x_t = torch.ones(N, dtype=y_t.dtype, device="cuda")

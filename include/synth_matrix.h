@@ -40,7 +40,7 @@ int synth_fem_fill(int gx, int gy, int gz, unsigned long long seed, int row0, in
 
 /* power-law: M = N = n, row degrees ~ 1.08/u clipped to [1, max_degree]
  * (Zipf-like, alpha = 2), columns half preferential (density ~ 1/sqrt(c)),
- * half uniform; duplicates inside a row are merged away.  fp32 values. */
+ * half uniform; a column may repeat inside a row (legal CSR).  fp32 values. */
 int synth_powerlaw_row_ptr(int n, int max_degree, unsigned long long seed, int *row_ptr);
 int synth_powerlaw_fill(int n, int max_degree, unsigned long long seed, int row0, int row1,
                         const int *row_ptr, int *col_idx, float *values);

@@ -615,21 +615,45 @@ __global__ __launch_bounds__(kBlock) void csr_long_pieces(int count, const int4 
                                                           const T *__restrict__ x,
                                                           T *__restrict__ partial) {
     using V2 = typename vec2<T>::type;
+    constexpr int kUnits = 8;  // 4096 entries = 16 loads per lane in flight per trip
     __shared__ T wave_part[kBlock / 64];
     if ((int)blockIdx.x >= count) return;
     const int t = threadIdx.x;
     const int4 d = pieces[blockIdx.x];
     const int n0 = d.y, n1 = d.z;
-    T acc = 0;
-    for (int e = (n0 & ~1) + 2 * t; e < n1; e += kStreamUnit) {
-        const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(col + e));
-        const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(val + e));
-        const T p0 = e >= n0 ? v.x * gather(x, c.x) : T(0);
-        const T p1 = e + 1 < n1 ? v.y * gather(x, c.y) : T(0);
-        acc += p0;
-        acc += p1;
+    T a0 = 0, a1 = 0;
+    int e0 = (n0 & ~1) + 2 * t;
+    // whole trips: every entry of the trip lies inside [n0, n1) except possibly the
+    // very first one of the piece (odd n0), which is masked
+    for (; e0 - 2 * t + kUnits * kStreamUnit <= n1; e0 += kUnits * kStreamUnit) {
+        v2i c[kUnits];
+        V2 v[kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e0 + u * kStreamUnit));
+            v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e0 + u * kStreamUnit));
+        }
+        T xv[2 * kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            xv[2 * u] = gather(x, c[u].x);
+            xv[2 * u + 1] = gather(x, c[u].y);
+        }
+        if (e0 < n0) v[0].x = T(0);  // only lane 0 of the first trip of an odd-start piece
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            a0 += v[u].x * xv[2 * u];
+            a1 += v[u].y * xv[2 * u + 1];
+        }
     }
-    acc = group_sum<64>(acc);
+    // remainder: bounded per entry
+    for (; e0 < n1; e0 += kStreamUnit) {
+        const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(col + e0));
+        const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(val + e0));
+        if (e0 >= n0) a0 += v.x * gather(x, c.x);
+        if (e0 + 1 < n1) a1 += v.y * gather(x, c.y);
+    }
+    T acc = group_sum<64>(a0 + a1);
     if ((t & 63) == 0) wave_part[t >> 6] = acc;
     __syncthreads();
     if (t == 0) {

@@ -224,34 +224,19 @@ static int cmp_int(const void *a, const void *b) {
     return (x > y) - (x < y);
 }
 
-/* distinct sorted columns of row r; returns how many (<= cap) */
-static int pl_row(int n, int max_degree, uint64_t seed, int r, int *buf) {
-    const int want = pl_degree(n, max_degree, seed, r);
+/* sorted columns of row r (a column may repeat: that is legal CSR and the SpMV
+ * kernels sum both entries); the row length is simply the drawn degree, so
+ * row_ptr needs no column generation */
+static void pl_row(int n, uint64_t seed, int r, int want, int *buf) {
     for (int s = 0; s < want; ++s) buf[s] = pl_column(n, seed, r, s);
-    qsort(buf, (size_t)want, sizeof(int), cmp_int);
-    int kept = 0;
-    for (int s = 0; s < want; ++s)
-        if (!kept || buf[s] != buf[kept - 1]) buf[kept++] = buf[s];
-    return kept;
+    if (want > 1) qsort(buf, (size_t)want, sizeof(int), cmp_int);
 }
 
 int synth_powerlaw_row_ptr(int n, int max_degree, unsigned long long seed, int *row_ptr) {
     if (n <= 0 || max_degree <= 0 || !row_ptr) return -1;
     int *len = row_ptr + 1;
-    int bad = 0;
-#pragma omp parallel
-    {
-        int *buf = (int *)malloc((size_t)max_degree * sizeof(int));
-        if (!buf) {
-#pragma omp atomic write
-            bad = 1;
-        } else {
-#pragma omp for schedule(dynamic, 4096)
-            for (int r = 0; r < n; ++r) len[r] = pl_row(n, max_degree, seed, r, buf);
-        }
-        free(buf);
-    }
-    if (bad) return -1;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < n; ++r) len[r] = pl_degree(n, max_degree, seed, r);
     row_ptr[0] = 0;
     long long run = 0;
     for (int r = 0; r < n; ++r) {
@@ -265,26 +250,15 @@ int synth_powerlaw_row_ptr(int n, int max_degree, unsigned long long seed, int *
 int synth_powerlaw_fill(int n, int max_degree, unsigned long long seed, int row0, int row1,
                         const int *row_ptr, int *col_idx, float *values) {
     if (n <= 0 || row0 < 0 || row1 < row0 || row1 > n) return -1;
+    (void)max_degree;
     const int e0 = row_ptr[row0];
-    int bad = 0;
-#pragma omp parallel
-    {
-        int *buf = (int *)malloc((size_t)max_degree * sizeof(int));
-        if (!buf) {
-#pragma omp atomic write
-            bad = 1;
-        } else {
-#pragma omp for schedule(dynamic, 4096)
-            for (int r = row0; r < row1; ++r) {
-                const int kept = pl_row(n, max_degree, seed, r, buf);
-                int at = row_ptr[r] - e0;
-                for (int s = 0; s < kept; ++s) {
-                    col_idx[at] = buf[s];
-                    values[at++] = (float)sym_value(seed, r, buf[s]);
-                }
-            }
-        }
-        free(buf);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int r = row0; r < row1; ++r) {
+        const int at = row_ptr[r] - e0;
+        const int want = row_ptr[r + 1] - row_ptr[r];
+        pl_row(n, seed, r, want, col_idx + at);  /* sort in place in the output */
+        for (int s = 0; s < want; ++s)
+            values[at + s] = (float)sym_value(seed ^ (uint64_t)s, r, col_idx[at + s]);
     }
-    return bad ? -1 : 0;
+    return 0;
 }

@@ -298,3 +298,25 @@ def test_full_size_properties_nlpkkt_like(gpu, oracle):
             rp = (row_ptr[lo:hi + 1] - e0).astype(np.int32)
             ref = oracle.csr_serial(rp, col[e0:e1], val[e0:e1], x1)
             assert_parity(y1[lo:hi], ref, rp, col[e0:e1], val[e0:e1], x1, what=f"rows {lo}..{hi}")
+
+
+def test_powerlaw_fp32_with_many_long_rows(gpu, oracle):
+    """BASELINE config 5's matrix family at 1/64 size (2^18 rows, ~4 M nnz, fp32): a large
+    share of the entries sits in rows far longer than the LDS stage, so this exercises the
+    piece / finish kernels at scale.  No reference counterpart (fp32): norm-wise 1e-5 against
+    the fp64-accumulated oracle."""
+    from sparsematrixvectormultiplication_amd import synth
+    n, row_ptr, col, val = synth.powerlaw(1 << 18, 1 << 16, 5)
+    assert val.dtype == np.float32 and np.diff(row_ptr).max() > 8192
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    y_ref = oracle.csr_f32_accum64(row_ptr, col, val, x)
+    scale = np.max(np.abs(y_ref))
+    with sp.CsrDevice(n, n, row_ptr, col, val) as dev:
+        info = dev.info()
+        assert info["long_rows"] > 0
+        for vname, variant in (("stream", sp.CSR_STREAM), ("subwave", sp.CSR_SUBWAVE)):
+            y = dev.spmv(x, variant).astype(np.float64)
+            assert np.max(np.abs(y - y_ref)) <= FP32_NORMWISE_RTOL * scale, vname
+        again = dev.spmv(x, sp.CSR_STREAM)
+        assert again.tobytes() == dev.spmv(x, sp.CSR_STREAM).tobytes()  # no atomics: reproducible

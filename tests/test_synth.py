@@ -1,0 +1,53 @@
+"""Stand-in matrix generators (include/synth_matrix.h): workload tooling for bench.py."""
+import numpy as np
+import pytest
+
+from sparsematrixvectormultiplication_amd import synth
+
+
+def to_dense(M, N, row_ptr, col, val):
+    A = np.zeros((M, N))
+    rows = np.repeat(np.arange(M), np.diff(row_ptr))
+    np.add.at(A, (rows, col), val)
+    return A
+
+
+@pytest.mark.parametrize("gen,grid", [(synth.kkt_like, (5, 6, 7)), (synth.fem_like, (3, 4, 5))])
+def test_stencil_standins_are_symmetric_sorted_and_sliceable(gen, grid):
+    M, row_ptr, col, val = gen(grid, 3)
+    assert row_ptr[0] == 0 and row_ptr[-1] == len(col) == len(val)
+    for r in range(M):
+        seg = col[row_ptr[r]:row_ptr[r + 1]]
+        assert len(seg) > 0 and np.all(np.diff(seg) > 0) and seg[0] >= 0 and seg[-1] < M
+    A = to_dense(M, M, row_ptr, col, val)
+    assert np.array_equal(A, A.T) and np.all(np.abs(val) < 1) and np.all(val != 0)
+    # any row range can be generated on its own (each GPU rank builds only its block)
+    for r0, r1 in ((0, M // 3), (M // 3, M - 5), (M - 5, M)):
+        M2, rp2, c2, v2 = gen(grid, 3, r0, r1)
+        assert M2 == M and np.array_equal(rp2, row_ptr)
+        assert np.array_equal(c2, col[row_ptr[r0]:row_ptr[r1]])
+        assert v2.tobytes() == val[row_ptr[r0]:row_ptr[r1]].tobytes()
+    # a different seed changes values, not structure
+    _, rp3, c3, v3 = gen(grid, 4)
+    assert np.array_equal(rp3, row_ptr) and np.array_equal(c3, col) and not np.array_equal(v3, val)
+
+
+def test_default_grids_match_the_suitesparse_shapes():
+    from sparsematrixvectormultiplication_amd import lib
+    assert lib().synth_kkt_rows(*synth.KKT_GRID) == 3542400   # nlpkkt120
+    assert lib().synth_fem_rows(*synth.FEM_GRID) == 62451     # cant
+    M, row_ptr, _, _ = synth.fem_like()
+    assert 60 < row_ptr[-1] / M < 75 and np.diff(row_ptr).max() == 81
+
+
+def test_powerlaw_standin():
+    n, row_ptr, col, val = synth.powerlaw(1 << 14, 1 << 10, 5)
+    deg = np.diff(row_ptr)
+    assert val.dtype == np.float32 and deg.min() >= 1 and deg.max() == 1 << 10
+    assert 8 < deg.mean() < 20 and np.median(deg) <= 3          # heavy tail
+    assert col.min() >= 0 and col.max() < n
+    for r in (0, 17, 4000, n - 1):
+        assert np.all(np.diff(col[row_ptr[r]:row_ptr[r + 1]]) >= 0)
+    n2, rp2, c2, v2 = synth.powerlaw(1 << 14, 1 << 10, 5, 1000, 9000)
+    assert np.array_equal(c2, col[row_ptr[1000]:row_ptr[9000]])
+    assert v2.tobytes() == val[row_ptr[1000]:row_ptr[9000]].tobytes()
