@@ -44,7 +44,7 @@ def test_powerlaw_standin():
     n, row_ptr, col, val = synth.powerlaw(1 << 14, 1 << 10, 5)
     deg = np.diff(row_ptr)
     assert val.dtype == np.float32 and deg.min() >= 1 and deg.max() == 1 << 10
-    assert 8 < deg.mean() < 20 and np.median(deg) <= 3          # heavy tail
+    assert 4 < deg.mean() < 20 and np.median(deg) <= 3          # heavy tail (mean grows with log(clip))
     assert col.min() >= 0 and col.max() < n
     for r in (0, 17, 4000, n - 1):
         assert np.all(np.diff(col[row_ptr[r]:row_ptr[r + 1]]) >= 0)
