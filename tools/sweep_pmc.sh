@@ -1,6 +1,9 @@
 #!/bin/bash
 OUT=gpurun_out/sweep; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/pass_a -- python3 tools/sweep_target.py > $OUT/a.log 2>&1
-rocprofv3 --pmc TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $OUT/pass_b -- python3 tools/sweep_target.py > $OUT/b.log 2>&1
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pass_c -- python3 tools/sweep_target.py > $OUT/c.log 2>&1
+PASSES=${SWEEP_PASSES:-"FETCH_SIZE,TCC_HIT_sum TCP_TCC_READ_REQ_sum,TA_BUSY_avr,TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_RDREQ_sum,TCC_MISS_sum,TCC_REQ_sum"}
+i=0
+for p in $PASSES; do
+  i=$((i+1))
+  rocprofv3 --pmc ${p//,/ } --output-format csv -d $OUT/pass_$i -- python3 tools/sweep_target.py > $OUT/$i.log 2>&1
+done
 python3 tools/sweep_report.py $OUT | tee gpurun_out/sweep_report.txt

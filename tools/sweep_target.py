@@ -14,9 +14,10 @@ from sparsematrixvectormultiplication_amd.device import set_tuning  # noqa: E402
 
 LAUNCHES = 6
 CONFIGS = []
-for xcd in (0, 8, 64, 512, 2048, -1):
-    for mode, name in ((0, "stream"), (1, "stream+gather"), (3, "all")):
-        CONFIGS.append((f"probe cap=4096 xcd={xcd} {name}", 4096, dict(stream_kind=10 + mode, stream_xcd=xcd)))
+for mode, name in ((0, "stream"), (1, "stream+gather"), (5, "stream+gather(L1 table)"), (3, "all"), (7, "all, gather(L1 table)")):
+    CONFIGS.append((f"probe cap=4096 {name}", 4096, dict(stream_kind=10 + mode, stream_xcd=0)))
+CONFIGS.append(("prod cap=4096", 4096, dict(stream_kind=0, stream_xcd=0)))
+CONFIGS.append(("walk cap=4096", 4096, dict(stream_kind=1, stream_xcd=0)))
 
 
 def main():
