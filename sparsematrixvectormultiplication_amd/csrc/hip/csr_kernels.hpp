@@ -30,6 +30,8 @@ constexpr int kStreamCapMax = 8192;  // largest nnz stage per workgroup (64 KiB 
 constexpr int kStreamUnit = 2 * kBlock;  // nnz one pass of the workgroup covers
 constexpr int kStreamRowsCap = 1024; // rows per workgroup (bounds the empty-row case)
 constexpr int kLongPiece = 8192;     // nnz per workgroup when one row is split
+constexpr int kBaseMask = ~3;        // a block is staged from the multiple-of-4 entry at or below its first
+                                     // (16-byte alignment of the column loads / LDS-DMA)
 
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chun
     const int t = threadIdx.x;
     const int4 d = desc[b];
     const int r0 = d.x, nrows = d.z;
-    const int base = d.y & ~1;
+    const int base = d.y & kBaseMask;
 
     // row extents of the first pass go out first so they are back early
     const int lanes = lanes_for_rows<BLOCK>(nrows);
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void csr_probe(int num_blocks, int xcd_chun
     const int t = threadIdx.x;
     const int4 d = desc[b];
     const int r0 = d.x, nrows = d.z;
-    const int base = d.y & ~1;
+    const int base = d.y & kBaseMask;
     const int lanes = lanes_for_rows<kBlock>(nrows);
     int seg_lo = 0, seg_hi = 0;
     if ((MODE & 2) && t / lanes < nrows) {
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int xc
     };
 
     auto issue = [&](v2i(&c)[kUnits], V2(&v)[kUnits], int first_entry) {
-        const int e_first = (first_entry & ~1) + 2 * t;
+        const int e_first = (first_entry & kBaseMask) + 2 * t;
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
             c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kUnit));
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int xc
     // after this block's gathers so both are in flight together
     auto step = [&](const int4 d, v2i(&c)[kUnits], V2(&v)[kUnits], auto prefetch) {
         const int r0 = d.x, nrows = d.z;
-        const int base = d.y & ~1;
+        const int base = d.y & kBaseMask;
         const int lanes = lanes_for_rows<kBlock>(nrows);
         int seg_lo = 0, seg_hi = 0;
         if (t / lanes < nrows) {
@@ -425,6 +427,160 @@ __global__ __launch_bounds__(kBlock) void csr_stream_pipe(int num_blocks, int xc
         step(d1, cB, vB, [] {});
     } else {
         step(d, cA, vA, [] {});
+    }
+}
+
+// ------------------------------------------------------------- stream, ring
+// Loads return IN ORDER per wavefront, so in every kernel above a wave's gathers queue
+// behind its own HBM stream (and a prefetched stream in front of the gathers makes them
+// wait a full HBM latency).  Here the two kinds of traffic live in different waves:
+//
+//   wave 0      LOADER: streams each block's (col, val) and its row_ptr segment straight
+//               into an LDS ring with LDS-DMA (global_load_lds: no VGPRs, lane-linear
+//               image), three blocks ahead, counted vmcnt, one raw s_barrier per block;
+//   waves 1-7   CONSUMERS: out of LDS only -- row extents, columns, values; their memory
+//               queue holds nothing but x gathers and y stores.
+//
+// Consumer lane mapping: a wave takes tiles of RW neighbouring rows x SW slices
+// (RW * SW = 64, SW from the block's mean row length so that a lane owns <= 8 entries);
+// lane = slice * RW + row: neighbouring lanes are neighbouring rows at the same position
+// (neighbouring x for stencil / FEM / banded matrices) and a row's partial sums are RW
+// lanes apart, summed in registers (strided_sum) -- no LDS round trip, no extra barrier.
+//
+// One persistent workgroup per CU, grid-stride over the blocks.  Blocks for this kernel
+// hold at most kRingRows rows (the staged row_ptr segment); rows longer than the stage go
+// to the piece kernels as usual.
+constexpr int kRingCap = 2048;
+constexpr int kRingRows = 320;   // staged row_ptr entries per block: rows <= kRingRows - 1
+constexpr int kRingBlock = 512;  // 1 loader + 7 consumer wavefronts
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <typename T>
+struct ring_slot {
+    T val[kRingCap];
+    int col[kRingCap];
+    int rp[kRingRows];
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (gfx9 encoding)
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// SLOTS ring slots, AHEAD (= SLOTS - 1) blocks in flight ahead of the consumers:
+// <4, 3> = 101 KiB of LDS, one workgroup per CU; <3, 2> = 76 KiB, two per CU (their
+// consumer chains interleave).
+template <typename T, bool NT, int SLOTS, int AHEAD>
+__global__ __launch_bounds__(kRingBlock) void csr_stream_ring(int num_blocks,
+                                                              const int4 *__restrict__ desc,
+                                                              const int *__restrict__ row_ptr,
+                                                              const int *__restrict__ col,
+                                                              const T *__restrict__ val,
+                                                              const T *__restrict__ x,
+                                                              T *__restrict__ y) {
+    static_assert(AHEAD == SLOTS - 1 && AHEAD >= 1 && AHEAD <= 3, "ring geometry");
+    __shared__ ring_slot<T> ring[SLOTS];
+    constexpr int kColDma = kRingCap * 4 / 1024;              // 1 KiB per wave-instruction
+    constexpr int kValDma = kRingCap * (int)sizeof(T) / 1024;
+    constexpr int kRpDma = kRingRows / 64;                    // 4-byte form: 256 B each
+    constexpr int kDma = kColDma + kValDma + kRpDma;          // LDS-DMA instructions per block
+    constexpr unsigned kAux = NT ? 2u : 0u;
+    static_assert((AHEAD - 1) * kDma <= 63, "the blocks allowed to stay in flight must fit the vmcnt counter");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int G = gridDim.x;
+    const int b0 = blockIdx.x;
+    if (b0 >= num_blocks) return;  // the whole workgroup
+    const int n = (num_blocks - 1 - b0) / G + 1;
+
+    if (wave == 0) {
+        // ------------------------------------------------------------ loader
+        auto issue = [&](int k) {
+            const int4 d = desc[b0 + k * G];
+            ring_slot<T> &s = ring[k % SLOTS];
+            const int base = d.y & kBaseMask;
+            constexpr int kValPerLane = 16 / (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < kColDma; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void *)(col + base + i * 256 + lane * 4),
+                                                 (lds_void *)(s.col + i * 256), 16, 0, kAux);
+#pragma unroll
+            for (int i = 0; i < kValDma; ++i)
+                __builtin_amdgcn_global_load_lds(
+                    (glb_void *)(val + base + i * 64 * kValPerLane + lane * kValPerLane),
+                    (lds_void *)(s.val + i * 64 * kValPerLane), 16, 0, kAux);
+#pragma unroll
+            for (int i = 0; i < kRpDma; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void *)(row_ptr + d.x + i * 64 + lane),
+                                                 (lds_void *)(s.rp + i * 64), 4, 0, 0);
+        };
+        for (int k = 0; k < AHEAD && k < n; ++k) issue(k);
+        for (int k = 0; k < n; ++k) {
+            // block k has landed when at most the blocks issued after it are outstanding
+            const int ahead = min(n - 1 - k, AHEAD - 1);
+            if (AHEAD >= 3 && ahead >= 2) wait_vmcnt<(AHEAD >= 3 ? 2 : 0) * kDma>();
+            else if (AHEAD >= 2 && ahead == 1) wait_vmcnt<(AHEAD >= 2 ? 1 : 0) * kDma>();
+            else wait_vmcnt<0>();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // block k is ready; consumers are done with block k-1
+            asm volatile("" ::: "memory");
+            if (k + AHEAD < n) issue(k + AHEAD);  // into the slot of block k-1
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumers
+    const int cw = wave - 1;
+    for (int k = 0; k < n; ++k) {
+        const int4 d = desc[b0 + k * G];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const ring_slot<T> &s = ring[k % SLOTS];
+        const int r0 = d.x, nrows = d.z;
+        const int base = d.y & kBaseMask;
+        const int mean = (d.w - d.y) / (nrows > 0 ? nrows : 1);
+        int sw = 1;
+        while (sw < 64 && sw * 8 < mean) sw <<= 1;  // slices per row: <= 8 entries per lane
+        const int rw = 64 / sw;
+        const int row_in = lane & (rw - 1), slice = lane / rw;
+        const int tiles = (nrows + rw - 1) / rw;
+        for (int tile = cw; tile < tiles; tile += kRingBlock / 64 - 1) {
+            const int row = tile * rw + row_in;
+            int lo = 0, hi = 0;
+            if (row < nrows) {
+                lo = s.rp[row] - base;
+                hi = s.rp[row + 1] - base;
+            }
+            T a0 = 0, a1 = 0;
+            for (int kk = lo + slice; __builtin_amdgcn_ballot_w64(kk < hi) != 0; kk += 8 * sw) {
+                int cc[8];
+                T xx[8], vv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = kk + j * sw;
+                    cc[j] = s.col[e < kRingCap ? e : kRingCap - 1];  // past the row: any staged column
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xx[j] = gather(x, cc[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = kk + j * sw;
+                    vv[j] = e < hi ? s.val[e] : T(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j & 1) a1 += vv[j] * xx[j];
+                    else a0 += vv[j] * xx[j];
+                }
+            }
+            const T acc = strided_sum(a0 + a1, rw);
+            if (slice == 0 && row < nrows) y[r0 + row] = acc;
+        }
     }
 }
 
@@ -486,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_walk(int num_blocks, int xc
     v2i c[kUnits];
     V2 v[kUnits];
     auto issue = [&](int first_entry) {
-        const int e_first = (first_entry & ~1) + 2 * t;
+        const int e_first = (first_entry & kBaseMask) + 2 * t;
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
             c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kStreamUnit));
@@ -533,7 +689,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_walk(int num_blocks, int xc
     // one block: its stream is in c/v on entry; `prefetch` refills c/v for a later block
     auto step_block = [&](const int4 d, auto prefetch) {
         const int r0 = d.x, nrows = d.z;
-        const int base = d.y & ~1;
+        const int base = d.y & kBaseMask;
         // lane -> (row, slice), rows fastest so that neighbouring lanes are neighbouring rows
         const int nr = nrows > 0 ? nrows : 1;  // a dummy block past the end has no rows
         const int slices = nrows < kBlock ? kBlock / nr : 1;

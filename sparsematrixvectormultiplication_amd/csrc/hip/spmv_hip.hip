@@ -110,6 +110,7 @@ struct spmv_csr_dev {
     void *partial = nullptr;
     int num_partial = 0;
     int stream_cap = 2048;
+    bool ring_ok = false;  // blocks respect the ring kernel's row limit
     // heuristics
     int lanes_per_row = 16;
     int auto_variant = SPMV_CSR_STREAM;
@@ -212,8 +213,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         if (value < -1) return fail("set_tuning: stream_xcd must be -1, 0 or a positive run length");
         g_stream_xcd = value;
     } else if (!strcmp(key, "stream_kind")) {
-        if ((value < 0 || value > 3) && (value < 10 || value > 17))
-            return fail("set_tuning: stream_kind must be 0..3 (or 10..13 for the ablation probes)");
+        if ((value < 0 || value > 4) && (value < 10 || value > 17))
+            return fail("set_tuning: stream_kind must be 0..4 (or 10..17 for the ablation probes)");
         g_stream_kind = value;
     } else if (!strcmp(key, "pipe_wgs_per_cu")) {
         if (value < 1 || value > 8) return fail("set_tuning: pipe_wgs_per_cu must be 1..8");
@@ -296,7 +297,7 @@ namespace {
 // (counted from the even entry at or below its first) fit `cap`.  A row that
 // cannot be staged is cut into pieces {row, first entry, end entry, slot} whose
 // partial sums csr_long_finish adds up per long row {row, first slot, pieces, 0}.
-void csr_build_blocks(int M, const int *rp, int cap, std::vector<int4> &desc,
+void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<int4> &desc,
                       std::vector<int4> &pieces, std::vector<int4> &long_rows) {
     desc.clear();
     pieces.clear();
@@ -305,8 +306,8 @@ void csr_build_blocks(int M, const int *rp, int cap, std::vector<int4> &desc,
     while (r < M) {
         const int n0 = rp[r];
         const int len = rp[r + 1] - n0;
-        const int base = n0 & ~1;
-        if (len > cap - 1) {
+        const int base = n0 & kBaseMask;
+        if (len > cap - 3) {
             const int first_slot = (int)pieces.size();
             for (int p = n0; p < rp[r + 1]; p += kLongPiece)
                 pieces.push_back(int4{r, p, std::min(p + kLongPiece, rp[r + 1]), (int)pieces.size()});
@@ -315,8 +316,8 @@ void csr_build_blocks(int M, const int *rp, int cap, std::vector<int4> &desc,
             continue;
         }
         int r1 = r;
-        while (r1 < M && r1 - r < kStreamRowsCap && rp[r1 + 1] - base <= cap &&
-               rp[r1 + 1] - rp[r1] <= cap - 1)
+        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap &&
+               rp[r1 + 1] - rp[r1] <= cap - 3)
             ++r1;
         desc.push_back(int4{r, n0, r1 - r, rp[r1]});
         r = r1;
@@ -368,14 +369,18 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     // larger stages amortise per-workgroup latency on big matrices; small ones need
     // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
     m->stream_cap = g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048);
-    csr_build_blocks(Ml, rp.data(), m->stream_cap, desc, pieces, long_rows);
+    // the ring kernel stages at most kRingRows - 1 rows per block; only worth it when such
+    // blocks are still (nearly) full, i.e. rows are not tiny
+    m->ring_ok = m->stream_cap == kRingCap && Ml > 0 && (double)nz / Ml >= 1.25 * kRingCap / (kRingRows - 1);
+    csr_build_blocks(Ml, rp.data(), m->stream_cap, m->ring_ok ? kRingRows - 1 : kStreamRowsCap, desc,
+                     pieces, long_rows);
     m->num_blocks = (int)desc.size();
     m->num_long = (int)long_rows.size();
     m->num_partial = (int)pieces.size();
     const int num_partial = m->num_partial;
 
     int rc = 0;
-    rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), 0);
+    rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), (size_t)kRingRows + 64);
     if (!rc) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
@@ -536,7 +541,17 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                 const int grid_blocks = chunk > 0 ? (m->num_blocks + 8 * chunk - 1) / (8 * chunk) * (8 * chunk)
                                                   : m->num_blocks;
                 const int cap = m->stream_cap, blk = g_stream_block;
-                if (g_stream_kind >= 10 && g_stream_kind <= 17 && (cap == 2048 || cap == 4096)) {
+                if (g_stream_kind == 4 && m->ring_ok) {
+                    // loader / consumer ring: one persistent 512-thread workgroup per CU
+                    const int wgs = std::max(1, std::min(g_num_cus * g_pipe_wgs_per_cu, m->num_blocks));
+                    if (g_pipe_wgs_per_cu >= 2) {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_ring<T, true, 3, 2>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_ring<T, false, 3, 2>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                    } else {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_ring<T, true, 4, 3>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_ring<T, false, 4, 3>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                    }
+                } else if (g_stream_kind >= 10 && g_stream_kind <= 17 && (cap == 2048 || cap == 4096)) {
                     // ablation probes (measurement only; y is not A x)
 #define SPMV_PROBE(CAP, MODE) hipLaunchKernelGGL((csr_probe<T, true, CAP, MODE>), dim3(grid_blocks), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS)
                     const int mode = g_stream_kind - 10;

@@ -70,6 +70,37 @@ __device__ __forceinline__ T group_sum(T v) {
     return v;
 }
 
+// Sum over the lanes that share (lane % RW), RW a power of two: the partial sums of one
+// row when RW neighbouring rows sit in neighbouring lanes and a row's slices are RW lanes
+// apart.  Every step must keep lane % RW, so the 4- and 8-steps rotate inside the 16-lane
+// DPP row (row_ror) instead of using the mirror patterns of group_sum.
+template <int STEP>
+__device__ __forceinline__ int rotate_i32(int v) {
+    if constexpr (STEP == 1) return dpp_i32<DPP_QUAD_XOR1>(v);
+    else if constexpr (STEP == 2) return dpp_i32<DPP_QUAD_XOR2>(v);
+    else if constexpr (STEP == 4) return dpp_i32<0x124>(v);   // row_ror:4
+    else if constexpr (STEP == 8) return dpp_i32<0x128>(v);   // row_ror:8
+    else return partner_i32<STEP>(v);                         // xor 16 / xor 32
+}
+template <int STEP>
+__device__ __forceinline__ double rotate(double v) {
+    return __hiloint2double(rotate_i32<STEP>(__double2hiint(v)), rotate_i32<STEP>(__double2loint(v)));
+}
+template <int STEP>
+__device__ __forceinline__ float rotate(float v) {
+    return __int_as_float(rotate_i32<STEP>(__float_as_int(v)));
+}
+template <typename T>
+__device__ __forceinline__ T strided_sum(T v, int rw) {  // rw wave-uniform
+    if (rw <= 1) v += rotate<1>(v);
+    if (rw <= 2) v += rotate<2>(v);
+    if (rw <= 4) v += rotate<4>(v);
+    if (rw <= 8) v += rotate<8>(v);
+    if (rw <= 16) v += rotate<16>(v);
+    if (rw <= 32) v += rotate<32>(v);
+    return v;
+}
+
 // Runtime-width dispatch for wave-uniform w.
 template <typename T>
 __device__ __forceinline__ T group_sum_rt(T v, int w) {

@@ -92,13 +92,14 @@ def test_stream_kernel_block_shapes_repeatable(gpu, oracle, mean, dtype):
     try:
         for cap, walk, blk in ((2048, 1, 256), (2048, 0, 256), (4096, 1, 256), (4096, 0, 256),
                                (4096, 0, 512), (8192, 0, 512), (8192, 0, 1024), (2048, 2, 256),
-                               (4096, 2, 256), (2048, 3, 256), (4096, 3, 256)):
+                               (4096, 2, 256), (2048, 3, 256), (4096, 3, 256), (2048, 4, 256), (2048, 4, 257)):
             set_tuning("stream_cap", cap)
             with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
                 dev.set_x(x)
                 if True:
                     set_tuning("stream_kind", walk)
-                    set_tuning("stream_block", blk)
+                    set_tuning("stream_block", blk if blk in (256, 512, 1024) else 256)
+                    set_tuning("pipe_wgs_per_cu", 2 if blk == 257 else (1 if walk == 4 else 5))
                     first = None
                     for rep in range(4):
                         sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * item)  # NaN pattern
@@ -117,6 +118,7 @@ def test_stream_kernel_block_shapes_repeatable(gpu, oracle, mean, dtype):
         set_tuning("stream_cap", 0)
         set_tuning("stream_kind", 0)
         set_tuning("stream_block", 256)
+        set_tuning("pipe_wgs_per_cu", 5)
 
 
 def test_csr_long_rows_are_split_and_summed(gpu, oracle):
@@ -131,7 +133,7 @@ def test_csr_long_rows_are_split_and_summed(gpu, oracle):
     y_ref = oracle.csr_serial(row_ptr, col, val, x)
     from sparsematrixvectormultiplication_amd.device import set_tuning
     try:
-        for cap, expect_long in ((2048, 6), (4096, 4), (8192, 3)):
+        for cap, expect_long in ((2048, 7), (4096, 4), (8192, 3)):
             set_tuning("stream_cap", cap)
             with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
                 assert dev.info()["long_rows"] == expect_long

@@ -27,12 +27,13 @@ algo = info["algo_bytes"]
 print(f"{which}: M={M} nnz={info['nz']} algo_bytes={algo} lanes_per_row={info['lanes_per_row']}")
 arms = [(f"prod cap={cap} block={blk} xcd={xcd}", dict(stream_kind=0, stream_block=blk, stream_nt=1, stream_xcd=xcd), cap, sp.CSR_STREAM)
         for cap, blk in ((2048, 256), (4096, 256), (4096, 512)) for xcd in (0,)]
-arms += [(f"walk cap={cap} wgs/cu={w}", dict(stream_kind=1, stream_nt=1, pipe_wgs_per_cu=w), cap, sp.CSR_STREAM)
-         for cap in (2048, 4096) for w in (2, 3, 4, 6, 8)]
+arms += [(f"walk cap={cap}", dict(stream_kind=1, stream_nt=1), cap, sp.CSR_STREAM) for cap in (2048, 4096)]
+arms += [(f"RING cap=2048 wgs/cu={w} nt={nt}", dict(stream_kind=4, stream_nt=nt, pipe_wgs_per_cu=w), 2048, sp.CSR_STREAM)
+         for w in (1, 2) for nt in (1, 0)]
 arms += [(f"pipe cap={cap} wgs/cu={w} nt={nt}", dict(stream_kind=2, stream_nt=nt, pipe_wgs_per_cu=w), cap, sp.CSR_STREAM)
          for cap in (2048, 4096) for w in (4,) for nt in (1,)]
-arms += [(f"PROBE cap={cap} " + name, dict(stream_kind=10 + mode), cap, sp.CSR_STREAM)
-         for cap in (2048, 4096) for mode, name in ((0, "stream only"), (1, "stream+gather"), (2, "stream+LDS sums"), (3, "all (= prod)"))]
+arms += [(f"PROBE cap=4096 " + name, dict(stream_kind=10 + mode), 4096, sp.CSR_STREAM)
+         for mode, name in ((0, "stream only"), (3, "all (= prod)"))]
 arms += [("subwave", {}, 2048, sp.CSR_SUBWAVE), ("wave_row", {}, 2048, sp.CSR_WAVE_ROW)]
 res = {a[0]: [] for a in arms}
 for r in range(rounds):
