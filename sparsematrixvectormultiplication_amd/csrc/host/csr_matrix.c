@@ -143,32 +143,40 @@ int convert_in_csr(const PreMatrix *pre, CSRMatrix *csr, const char *matrix_name
         const int len = csr->row_ptr[r + 1] - csr->row_ptr[r];
         if (len > longest) longest = len;
     }
-    ColVal *scratch = (ColVal *)malloc((size_t)(longest ? longest : 1) * sizeof(ColVal));
-    int *keep_c = (int *)malloc((size_t)(longest ? longest : 1) * sizeof(int));
-    double *keep_v = (double *)malloc((size_t)(longest ? longest : 1) * sizeof(double));
-    if (!scratch || !keep_c || !keep_v) {
-        printf("Errore di allocazione memoria nella conversione CSR\n");
+    /* rows are independent: order them with all threads, each with its own scratch */
+    int bad_alloc = 0;
+#pragma omp parallel
+    {
+        ColVal *scratch = (ColVal *)malloc((size_t)(longest ? longest : 1) * sizeof(ColVal));
+        int *keep_c = (int *)malloc((size_t)(longest ? longest : 1) * sizeof(int));
+        double *keep_v = (double *)malloc((size_t)(longest ? longest : 1) * sizeof(double));
+        if (!scratch || !keep_c || !keep_v) {
+#pragma omp atomic write
+            bad_alloc = 1;
+        } else {
+#pragma omp for schedule(dynamic, 2048)
+            for (long long r = 0; r < (long long)M; ++r) {
+                const int s = csr->row_ptr[r], len = csr->row_ptr[r + 1] - s;
+                if (len < 2) continue;
+                memcpy(keep_c, csr->col_idx + s, (size_t)len * sizeof(int));
+                memcpy(keep_v, csr->values + s, (size_t)len * sizeof(double));
+                if (order_row_fast(csr->col_idx + s, csr->values + s, len, scratch)) {
+                    /* repeated column: tie order is defined by the reference's scheme */
+                    memcpy(csr->col_idx + s, keep_c, (size_t)len * sizeof(int));
+                    memcpy(csr->values + s, keep_v, (size_t)len * sizeof(double));
+                    sort_row(csr->col_idx + s, csr->values + s, 0, (size_t)len - 1);
+                }
+            }
+        }
         free(scratch);
         free(keep_c);
         free(keep_v);
+    }
+    if (bad_alloc) {
+        printf("Errore di allocazione memoria nella conversione CSR\n");
         free_csr_matrix(csr);
         return -1;
     }
-    for (size_t r = 0; r < M; ++r) {
-        const int s = csr->row_ptr[r], len = csr->row_ptr[r + 1] - s;
-        if (len < 2) continue;
-        memcpy(keep_c, csr->col_idx + s, (size_t)len * sizeof(int));
-        memcpy(keep_v, csr->values + s, (size_t)len * sizeof(double));
-        if (order_row_fast(csr->col_idx + s, csr->values + s, len, scratch)) {
-            /* repeated column: tie order is defined by the reference's scheme */
-            memcpy(csr->col_idx + s, keep_c, (size_t)len * sizeof(int));
-            memcpy(csr->values + s, keep_v, (size_t)len * sizeof(double));
-            sort_row(csr->col_idx + s, csr->values + s, 0, (size_t)len - 1);
-        }
-    }
-    free(scratch);
-    free(keep_c);
-    free(keep_v);
     return 0;
 }
 

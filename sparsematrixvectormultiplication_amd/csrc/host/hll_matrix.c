@@ -131,18 +131,35 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
         cols[dst] = pre->J[e];
         vals[dst] = pre->val[e];
     }
-    tc = (int *)malloc((size_t)(longest ? longest : 1) * sizeof(int));
-    tv = (double *)malloc((size_t)(longest ? longest : 1) * sizeof(double));
-    if (!tc || !tv) {
-        printf("Errore di allocazione memoria per sorted_elements\n");
-        goto fail;
-    }
-    for (int r = 0; r < M; ++r) {
-        const int len = row_off[r + 1] - row_off[r];
-        if (len > 1) order_pairs_stable(cols + row_off[r], vals + row_off[r], len, tc, tv);
+    /* rows are independent: order them with all threads (per-thread merge scratch) */
+    {
+        int bad_alloc = 0;
+#pragma omp parallel
+        {
+            int *my_c = (int *)malloc((size_t)(longest ? longest : 1) * sizeof(int));
+            double *my_v = (double *)malloc((size_t)(longest ? longest : 1) * sizeof(double));
+            if (!my_c || !my_v) {
+#pragma omp atomic write
+                bad_alloc = 1;
+            } else {
+#pragma omp for schedule(dynamic, 2048)
+                for (int r = 0; r < M; ++r) {
+                    const int len = row_off[r + 1] - row_off[r];
+                    if (len > 1) order_pairs_stable(cols + row_off[r], vals + row_off[r], len, my_c, my_v);
+                }
+            }
+            free(my_c);
+            free(my_v);
+        }
+        if (bad_alloc) {
+            printf("Errore di allocazione memoria per sorted_elements\n");
+            goto fail;
+        }
     }
 
-    /* one ELLPACK slab per hack, row-major, padded */
+    /* one ELLPACK slab per hack, row-major, padded; hacks are independent */
+    int hack_failed = 0;
+#pragma omp parallel for schedule(dynamic, 256)
     for (int b = 0; b < num_blocks; ++b) {
         const int r0 = b * HACK_SIZE;
         const int r1 = (b == num_blocks - 1) ? M : r0 + HACK_SIZE;
@@ -163,8 +180,9 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
         blk->JA = (int *)malloc(slots * sizeof(int));
         blk->AS = (double *)malloc(slots * sizeof(double));
         if (!blk->JA || !blk->AS) {
-            printf("ERRORE: Allocazione fallita per il blocco %d\n", b);
-            goto fail;
+#pragma omp atomic write
+            hack_failed = 1;
+            continue;
         }
         for (int r = r0; r < r1; ++r) {
             const int len = row_off[r + 1] - row_off[r];
@@ -179,6 +197,10 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
                 as[j] = 0.0;
             }
         }
+    }
+    if (hack_failed) {
+        printf("ERRORE: Allocazione fallita per un blocco HLL\n");
+        goto fail;
     }
     free(row_off);
     free(cursor);
