@@ -5,6 +5,7 @@
 set -e
 TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also $*"
