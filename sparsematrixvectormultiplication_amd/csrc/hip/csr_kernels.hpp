@@ -191,7 +191,7 @@ __device__ __forceinline__ void sum_rows_from_lds(const T *prod, const int *__re
 
 // One workgroup per block: stage products, sum rows.
 template <typename T, bool NT, int CAP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chunk_and_prio,
+__global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chunk,
                                                     const int4 *__restrict__ desc,
                                                     const int *__restrict__ row_ptr,
                                                     const int *__restrict__ col,
@@ -202,10 +202,6 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chun
     constexpr int kUnits = CAP / kUnit;
     __shared__ T prod[CAP];
 
-    // low 24 bits: blocks per XCD run; bit 24: raise the wave's issue priority once its
-    // stream loads are out (A/B knob "stream_prio")
-    const int xcd_chunk = xcd_chunk_and_prio & 0xFFFFFF;
-    const bool prio = (xcd_chunk_and_prio >> 24) & 1;
     const int b = xcd_chunked(blockIdx.x, xcd_chunk);
     if (b >= num_blocks) return;  // whole workgroup leaves together
     const int t = threadIdx.x;
@@ -232,7 +228,6 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chun
             c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kUnit));
             v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
         }
-        if (prio) __builtin_amdgcn_s_setprio(3);  // older phases first: finish and free the slot
         T xv[2 * kUnits];
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {

@@ -30,8 +30,8 @@ for cap in (2048, 4096, 8192):
 info = devs[2048].info()
 algo = info["algo_bytes"]
 print(f"{which}: M={M} nnz={info['nz']} algo_bytes={algo} lanes_per_row={info['lanes_per_row']}")
-arms = [(f"prod cap={cap} block={blk} prio={pr}", dict(stream_kind=0, stream_block=blk, stream_nt=1, stream_xcd=0, stream_prio=pr), cap, sp.CSR_STREAM)
-        for cap, blk in ((2048, 256), (4096, 256), (4096, 512)) for pr in (0, 1)]
+arms = [(f"prod cap={cap} block={blk}", dict(stream_kind=0, stream_block=blk, stream_nt=1, stream_xcd=0), cap, sp.CSR_STREAM)
+        for cap, blk in ((2048, 256), (4096, 256), (4096, 512))]
 arms += [(f"walk cap={cap}", dict(stream_kind=1, stream_nt=1), cap, sp.CSR_STREAM) for cap in (2048, 4096)]
 arms += [(f"RING cap=2048 wgs/cu={w} nt={nt}", dict(stream_kind=4, stream_nt=nt, pipe_wgs_per_cu=w), 2048, sp.CSR_STREAM)
          for w in (1, 2) for nt in (1, 0)]
@@ -43,7 +43,6 @@ arms += [("subwave", {}, 2048, sp.CSR_SUBWAVE), ("wave_row", {}, 2048, sp.CSR_WA
 res = {a[0]: [] for a in arms}
 for r in range(rounds):
     for name, knobs, cap, variant in arms:
-        set_tuning("stream_prio", 0)
         for k, v in knobs.items():
             set_tuning(k, v)
         ms = devs[cap].time(variant, warmup=2, iters=20, zero_y=False)
