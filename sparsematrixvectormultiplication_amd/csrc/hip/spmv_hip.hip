@@ -42,7 +42,6 @@ int g_stream_xcd = 0;     // blocks per XCD run (xcd_chunked); 0 = dispatch orde
 int g_stream_kind = 0;     // 0 = csr_stream (products), 1 = csr_stream_rows (row walk), 2 = csr_stream_pipe
 int g_pipe_wgs_per_cu = 5; // resident workgroups per CU the persistent grid is sized for
 int g_num_cus = 256;
-int g_stream_prio = 0;     // csr_stream: s_setprio(3) after the stream loads are issued    // 1 = csr_stream_rows (row walk out of LDS), 0 = csr_stream (products)
 
 int fail(const char *fmt, ...) {
     va_list ap;
@@ -213,8 +212,6 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "stream_xcd")) {
         if (value < -1) return fail("set_tuning: stream_xcd must be -1, 0 or a positive run length");
         g_stream_xcd = value;
-    } else if (!strcmp(key, "stream_prio")) {
-        g_stream_prio = value != 0;
     } else if (!strcmp(key, "stream_kind")) {
         if ((value < 0 || value > 4) && (value < 10 || value > 17))
             return fail("set_tuning: stream_kind must be 0..4 (or 10..17 for the ablation probes)");
@@ -533,7 +530,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
 #define SPMV_ARGS m->desc, m->row_ptr, m->col, (const T *)m->val, x, y
 #define SPMV_LAUNCH_PROD(NT, CAP, BLOCK)                                                          \
     hipLaunchKernelGGL((csr_stream<T, NT, CAP, BLOCK>), dim3(grid_blocks), dim3(BLOCK), 0, s,      \
-                       m->num_blocks, chunk | (g_stream_prio ? 1 << 24 : 0), SPMV_ARGS)
+                       m->num_blocks, chunk, SPMV_ARGS)
 #define SPMV_LAUNCH_FLAGS(MACRO, ...)              \
     do {                                           \
         if (g_stream_nt) MACRO(true, __VA_ARGS__); \
