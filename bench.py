@@ -86,7 +86,9 @@ def parse_args():
     p.add_argument("--mtx", default=os.environ.get("SPMV_MTX"))
     p.add_argument("--grid", default=None, help="nx,ny,nz of the stand-in generator")
     p.add_argument("--powerlaw-n", type=int, default=1 << 24)
-    p.add_argument("--exchange", default="rccl", choices=["rccl", "torch"])
+    p.add_argument("--exchange", default="rccl", choices=["rccl", "torch", "gloo-host"],
+                   help="gloo-host: debug transport through host memory (several ranks may share one GPU)")
+    p.add_argument("--check", action="store_true", help="every rank checks the gathered y against the oracle")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-also", action="store_true", help="skip the cant CSR/HLL side measurements")
     p.add_argument("--cpu-iters", type=int, default=0, help="0 = size for ~10 s")
@@ -276,7 +278,10 @@ def main():
     sp.hip_init(local_rank)
     dev_name, cus, _ = sp.device_name()
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.exchange == "gloo-host":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier_sync():
         if world > 1:
@@ -331,6 +336,8 @@ def main():
                     comm = None
                 exchange = "torch"
                 log(f"[rank {rank}] using torch.distributed for the all-gatherv")
+        if exchange == "gloo-host":
+            y_host = torch.zeros(M, dtype=torch.float32 if vb == 4 else torch.float64)
         if exchange == "torch":
             y_t = torch.zeros(M, dtype=torch.float32 if vb == 4 else torch.float64, device="cuda")
             x_t = torch.ones(N, dtype=y_t.dtype, device="cuda")
@@ -353,6 +360,23 @@ def main():
         ms_kernel, ms_xchg = dev.step_time(bounds, variant, 0, K)
         barrier_sync()
         wall = time.perf_counter() - t
+    elif exchange == "gloo-host":
+        import ctypes as C
+
+        def host_step():
+            t_k = dev.time(variant, 0, 1, zero_y=False)
+            y_host.copy_(torch.from_numpy(dev.get_y()))
+            allgatherv_rows_torch(y_host, bounds)
+            sp.lib().spmv_hip_memcpy_h2d(C.c_void_p(dev.y_ptr), C.c_void_p(y_host.data_ptr()), M * vb)
+            return t_k[0]
+        for _ in range(W):
+            host_step()
+        barrier_sync()
+        t = time.perf_counter()
+        ms_kernel = np.array([host_step() for _ in range(K)])
+        barrier_sync()
+        wall = time.perf_counter() - t
+        ms_xchg = np.zeros(K)
     else:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]
 
@@ -379,7 +403,8 @@ def main():
     stats = torch.tensor([wall, float(np.mean(ms_kernel)), float(np.mean(ms_xchg)) if ms_xchg is not None else 0.0,
                           float(info["algo_bytes"]), float(info["nz"])], dtype=torch.float64)
     if world > 1:
-        stats = stats.cuda()
+        if exchange != "gloo-host":
+            stats = stats.cuda()
         gathered = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(gathered, stats)
         per_rank = torch.stack(gathered).cpu().numpy()
@@ -388,7 +413,20 @@ def main():
     wall_max = float(per_rank[:, 0].max())
 
     # ---- parity spot check on this rank's rows (checker: the oracle)
-    y_gpu = dev.get_y()
+    y_gpu = dev.get_y() if exchange != "torch" else y_t.cpu().numpy()
+    if args.check:
+        # every rank: the gathered y against the serial oracle on the WHOLE matrix
+        from oracle.oracle import Oracle
+        if args.workload == "nlpkkt" and not args.mtx:
+            grid = tuple(int(v) for v in args.grid.split(",")) if args.grid else synth.KKT_GRID
+            _, rp_all, col_all, val_all = synth.kkt_like(grid, 2)
+        else:
+            raise SystemExit("--check is implemented for the synthetic nlpkkt workload")
+        y_ref = Oracle().csr_serial(rp_all, col_all, val_all, np.ones(N))
+        err = float(np.max(np.abs(y_gpu - y_ref)) / max(np.max(np.abs(y_ref)), 1e-300))
+        log(f"[rank {rank}] check: max|y - y_ref| / max|y_ref| = {err:.3e} over {M} rows (rows {r0}..{r1} computed here)")
+        if not err <= 1e-10:
+            raise SystemExit(f"[rank {rank}] gathered y differs from the oracle: {err:.3e}")
     result = None
     if rank == 0:
         ms_step = wall_max / K * 1e3
@@ -413,7 +451,8 @@ def main():
                        "rows": M, "cols": N, "nnz": nnz_total, "x": "ones",
                        "kernel": kernel_name, "parallelism": f"row-block x{world}" if world > 1 else "1 GPU",
                        "exchange": {"none": "none", "rccl": "RCCL all-gatherv(y), C-ABI communicator",
-                                    "torch": "RCCL all-gatherv(y) via torch.distributed"}[exchange],
+                                    "torch": "RCCL all-gatherv(y) via torch.distributed",
+                                    "gloo-host": "DEBUG: all-gatherv(y) through host memory (gloo)"}[exchange],
                        "nnz_imbalance_max_over_mean": round(float(per_rank[:, 4].max() / per_rank[:, 4].mean()), 4),
                        "device": dev_name},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),

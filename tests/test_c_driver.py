@@ -42,3 +42,28 @@ def test_c_driver_fails_loudly_without_a_gpu(tmp_path):
         pytest.skip("a HIP device is present")
     proc = subprocess.run([DRIVER, "--out", str(tmp_path / "r"), GOLDEN], capture_output=True, text=True)
     assert proc.returncode == 1 and "no usable HIP device" in proc.stderr
+
+
+@pytest.mark.gpu
+def test_bench_row_partitioned_two_ranks_sharing_the_gpu(gpu):
+    """The N > 1 host path of bench.py on real kernels: two ranks (both on this box's one
+    GPU -- RCCL refuses that, so the exchange goes through host memory with gloo), each
+    uploads only its nnz-balanced row block, and every rank checks the gathered y against
+    the oracle.  Everything except the RCCL transport itself is what the 8-GPU run executes."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "24,24,24", "--exchange", "gloo-host",
+           "--check", "--no-cpu-baseline"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["parallelism"] == "row-block x2"
+    assert proc.stderr.count("check: max|y - y_ref|") == 2
