@@ -107,112 +107,118 @@ __device__ __forceinline__ void stage_units(T *prod, const int *__restrict__ JA,
 // Stage slots [from, from + count) of the flat slab as products in LDS.
 // `from` is even; prod[k] receives slot from + k.  The number of units is
 // wave-uniform, so the dispatch below is scalar branching, not predication.
-template <typename T, bool NT>
+template <typename T, bool NT, int MAXU>
 __device__ __forceinline__ void stage_products(T *prod, const int *__restrict__ JA,
                                                const T *__restrict__ AS,
                                                const T *__restrict__ x, long long from,
                                                int count) {
-    int units = (count + kStreamUnit - 1) / kStreamUnit;
-    int k0 = 0;
-    while (units >= 4) {
-        stage_units<T, NT, 4>(prod, JA, AS, x, from, k0, count);
-        k0 += 4 * kStreamUnit;
-        units -= 4;
+    // all units of the range in ONE batch: every load of the block is in flight together
+    // instead of one HBM latency per batch.  MAXU (2, 4, 6 or 8 units of 512 slots) is
+    // picked at upload from the largest workgroup of the matrix, so small hacks do not pay
+    // the registers of an 8-unit batch.
+    const int units = (count + kStreamUnit - 1) / kStreamUnit;
+    if (units <= MAXU) {
+        switch (units) {
+            case 1: stage_units<T, NT, 1>(prod, JA, AS, x, from, 0, count); break;
+            case 2: stage_units<T, NT, 2>(prod, JA, AS, x, from, 0, count); break;
+            case 3: if constexpr (MAXU >= 3) stage_units<T, NT, 3>(prod, JA, AS, x, from, 0, count); break;
+            case 4: if constexpr (MAXU >= 4) stage_units<T, NT, 4>(prod, JA, AS, x, from, 0, count); break;
+            case 5: if constexpr (MAXU >= 5) stage_units<T, NT, 5>(prod, JA, AS, x, from, 0, count); break;
+            case 6: if constexpr (MAXU >= 6) stage_units<T, NT, 6>(prod, JA, AS, x, from, 0, count); break;
+            case 7: if constexpr (MAXU >= 7) stage_units<T, NT, 7>(prod, JA, AS, x, from, 0, count); break;
+            case 8: if constexpr (MAXU >= 8) stage_units<T, NT, 8>(prod, JA, AS, x, from, 0, count); break;
+            default: break;
+        }
+        return;
     }
-    if (units == 3) stage_units<T, NT, 3>(prod, JA, AS, x, from, k0, count);
-    else if (units == 2) stage_units<T, NT, 2>(prod, JA, AS, x, from, k0, count);
-    else if (units == 1) stage_units<T, NT, 1>(prod, JA, AS, x, from, k0, count);
+    // more than MAXU units (only the row-chunk path of an oversized hack gets here)
+    int k0 = 0, left = units;
+    while (left >= MAXU) {
+        stage_units<T, NT, MAXU>(prod, JA, AS, x, from, k0, count);
+        k0 += MAXU * kStreamUnit;
+        left -= MAXU;
+    }
+    for (; left > 0; --left, k0 += kStreamUnit) stage_units<T, NT, 1>(prod, JA, AS, x, from, k0, count);
 }
 
-// Workgroup b owns hacks [hblk[b], hblk[b+1]).  Host packing (hll_build_blocks)
-// keeps the slots of a multi-hack workgroup within kHllCap; a single hack
-// larger than that is walked in row chunks (or, if even one row does not fit,
-// row by row with register accumulation).
-template <typename T, bool NT>
-__global__ __launch_bounds__(kBlock) void hll_lds(int M, const int *__restrict__ hblk,
+// Workgroup b owns the consecutive rows [desc[b].x, desc[b].x + desc[b].y) of the matrix,
+// i.e. one contiguous window of the flat slab starting at slot (desc[b].w : desc[b].z)
+// -- rows of neighbouring hacks, each with its own hack's maxnz.  Host packing
+// (hll_build_blocks) fills the window up to the LDS stage, so workgroups are as full as
+// the CSR kernel's whatever maxnz is; a row that alone exceeds the stage gets a workgroup
+// of its own and is accumulated in registers.
+//
+// LDS is dynamic: `stage_slots` (+2) products, sized at upload to the largest workgroup
+// (at most kHllCap), so matrices with short rows keep more workgroups resident.
+template <typename T, bool NT, int MAXU>
+__global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *__restrict__ desc,
                                                   const long long *__restrict__ hack_off,
                                                   const int *__restrict__ maxnz,
                                                   const int *__restrict__ JA,
                                                   const T *__restrict__ AS,
                                                   const T *__restrict__ x, T *__restrict__ y) {
-    __shared__ T prod[kHllCap + 2];
-    __shared__ T wave_part[kBlock / 64];
+    extern __shared__ __align__(16) unsigned char hll_dyn_lds[];
+    T *wave_part = reinterpret_cast<T *>(hll_dyn_lds);                   // [kBlock / 64]
+    T *prod = reinterpret_cast<T *>(hll_dyn_lds) + 16 / sizeof(T) * 2;  // [stage_slots + 2]
     const int t = threadIdx.x;
-    const int h0 = hblk[blockIdx.x], h1 = hblk[blockIdx.x + 1];
-    const long long base = hack_off[h0];
-    const long long span = hack_off[h1] - base;
-    const int row_first = h0 * kHack;
-    const int row_last = min(h1 * kHack, M);  // exclusive
-    const int nrows = row_last - row_first;
+    const int4 d = desc[blockIdx.x];
+    const int row_first = d.x, nrows = d.y;
+    const long long first_slot = ((long long)d.w << 32) | (unsigned)d.z;
+    const long long base = first_slot & ~1LL;  // 8/16-byte aligned stage loads
 
-    if (span <= kHllCap) {
-        stage_products<T, NT>(prod, JA, AS, x, base, (int)span);
-        __syncthreads();
-        int lanes = 1;
-        if (nrows <= kBlock / 2) {
-            lanes = 1 << (31 - __clz(kBlock / (nrows > 0 ? nrows : 1)));
-            if (lanes > 64) lanes = 64;
-        }
-        const int rows_per_pass = kBlock / lanes;
-        const int my_row = t / lanes, my_lane = t % lanes;
-        for (int first = 0; first < nrows; first += rows_per_pass) {
-            const int q = first + my_row;
+    // slot range of a row relative to base
+    auto row_range = [&](int q, int &lo, int &m) {
+        const int r = row_first + q;
+        const int h = r / kHack;
+        m = maxnz[h];
+        lo = (int)(hack_off[h] + (long long)(r % kHack) * m - base);
+    };
+
+    if (nrows == 1) {
+        int lo1, m1;
+        row_range(0, lo1, m1);
+        if (lo1 + m1 > stage_slots) {
+            // a single row longer than the stage: whole workgroup, registers only
+            const long long at = base + lo1;
             T acc = 0;
-            if (q < nrows) {
-                const int h = h0 + q / kHack, i = q % kHack;
-                const int m = maxnz[h];
-                const int lo = (int)(hack_off[h] - base) + i * m;
-                acc = lds_strided_sum(prod, lo, lo + m, my_lane, lanes);
-            }
-            acc = group_sum_rt(acc, lanes);
-            if (my_lane == 0 && q < nrows) y[row_first + q] = acc;
-        }
-        return;
-    }
-
-    // one oversized hack
-    const int m = maxnz[h0];
-    if (m <= kHllCap) {
-        const int rows_per_chunk = kHllCap / m;  // >= 1, < 32 here
-        int lanes = 1 << (31 - __clz(kBlock / rows_per_chunk));
-        if (lanes > 64) lanes = 64;
-        const int my_row = t / lanes, my_lane = t % lanes;
-        for (int i0 = 0; i0 < nrows; i0 += rows_per_chunk) {
-            const int rows = min(rows_per_chunk, nrows - i0);
-            const long long from = base + (long long)i0 * m;
-            const long long from_even = from & ~1LL;
-            const int shift = (int)(from - from_even);
-            __syncthreads();  // previous chunk fully consumed
-            stage_products<T, NT>(prod, JA, AS, x, from_even, rows * m + shift);
+            for (int j = t; j < m1; j += kBlock) acc += AS[at + j] * gather(x, JA[at + j]);
+            acc = group_sum<64>(acc);
+            if ((t & 63) == 0) wave_part[t >> 6] = acc;
             __syncthreads();
-            for (int first = 0; first < rows; first += kBlock / lanes) {
-                const int q = first + my_row;
-                T acc = 0;
-                if (q < rows) {
-                    const int lo = shift + q * m;
-                    acc = lds_strided_sum(prod, lo, lo + m, my_lane, lanes);
-                }
-                acc = group_sum_rt(acc, lanes);
-                if (my_lane == 0 && q < rows) y[row_first + i0 + q] = acc;
+            if (t == 0) {
+                T s = wave_part[0];
+                for (int w = 1; w < kBlock / 64; ++w) s += wave_part[w];
+                y[row_first] = s;
             }
+            return;
         }
-        return;
     }
 
-    // rows longer than the stage: whole workgroup per row, registers only
-    for (int i = 0; i < nrows; ++i) {
-        const long long at = base + (long long)i * m;
-        T acc = 0;
-        for (int j = t; j < m; j += kBlock) acc += AS[at + j] * gather(x, JA[at + j]);
-        acc = group_sum<64>(acc);
-        __syncthreads();
-        if ((t & 63) == 0) wave_part[t >> 6] = acc;
-        __syncthreads();
-        if (t == 0) {
-            T s = wave_part[0];
-            for (int w = 1; w < kBlock / 64; ++w) s += wave_part[w];
-            y[row_first + i] = s;
+    // lane -> row of the first pass and its slot range, looked up BEFORE the stream so
+    // the two small global loads ride along with it
+    int lanes = 1;
+    if (nrows <= kBlock / 2) {
+        lanes = 1 << (31 - __clz(kBlock / (nrows > 0 ? nrows : 1)));
+        if (lanes > 64) lanes = 64;
+    }
+    const int rows_per_pass = kBlock / lanes;
+    const int my_row = t / lanes, my_lane = t % lanes;
+    int lo = 0, m_row = 0;
+    if (my_row < nrows) row_range(my_row, lo, m_row);
+    // the window ends with its last row
+    int last_lo, last_m;
+    row_range(nrows - 1, last_lo, last_m);
+    stage_products<T, NT, MAXU>(prod, JA, AS, x, base, last_lo + last_m);
+    __syncthreads();
+    for (int first = 0; first < nrows; first += rows_per_pass) {
+        const int q = first + my_row;
+        if (first > 0) {
+            lo = m_row = 0;
+            if (q < nrows) row_range(q, lo, m_row);
         }
+        T acc = lds_strided_sum(prod, lo, lo + m_row, my_lane, lanes);
+        acc = group_sum_rt(acc, lanes);
+        if (my_lane == 0 && q < nrows) y[row_first + q] = acc;
     }
 }
 

@@ -126,8 +126,9 @@ struct spmv_hll_dev {
     int *maxnz = nullptr;           // [hacks]
     int *JA = nullptr;
     double *AS = nullptr;
-    int *hblk = nullptr;  // [num_blocks + 1]
+    int4 *hdesc = nullptr;  // [num_blocks] {first row, rows, first slot lo, first slot hi}
     int num_blocks = 0;
+    int stage_slots = kHllCap;  // LDS stage of hll_lds: the largest workgroup, <= kHllCap
     double *x = nullptr;
     double *y = nullptr;
     int lanes_per_row = 8;
@@ -678,17 +679,28 @@ extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int i
 // ----------------------------------------------------------------- HLL
 namespace {
 
-// group consecutive hacks into workgroups of at most kHllCap slots
-void hll_build_blocks(int hacks, const long long *off, std::vector<int> &hblk) {
-    hblk.clear();
-    int h = 0;
-    while (h < hacks) {
-        hblk.push_back(h);
-        int h1 = h + 1;
-        while (h1 < hacks && off[h1 + 1] - off[h] <= kHllCap && h1 - h < 8) ++h1;
-        h = h1;
+// Cut the rows of the flat slab into workgroup windows for hll_lds: consecutive rows whose
+// slots, counted from the even slot at or below the first row's start, fit `cap` (at most
+// kStreamRowsCap rows).  A row that alone does not fit gets a window of its own.  Returns
+// the widest window (in slots, from its even base).
+long long hll_build_blocks(int M, int hacks, const long long *off, const int *mz, int cap,
+                           std::vector<int4> &desc) {
+    desc.clear();
+    (void)hacks;
+    long long widest = 0;
+    auto start_of = [&](int r) { return off[r / kHack] + (long long)(r % kHack) * mz[r / kHack]; };
+    int r = 0;
+    while (r < M) {
+        const long long s0 = start_of(r);
+        const long long base = s0 & ~1LL;
+        int r1 = r + 1;  // the first row is always taken (even if it alone exceeds cap)
+        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap) ++r1;
+        const long long span = start_of(r1 - 1) + mz[(r1 - 1) / kHack] - base;
+        if (r1 - r > 1 || span <= cap) widest = std::max(widest, span);
+        desc.push_back(int4{r, r1 - r, (int)(s0 & 0xffffffffLL), (int)(s0 >> 32)});
+        r = r1;
     }
-    hblk.push_back(hacks);
+    return widest;
 }
 
 }  // namespace
@@ -733,8 +745,11 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
         memcpy(&ja[(size_t)off[h]], b->JA, s * sizeof(int));
         memcpy(&as[(size_t)off[h]], b->AS, s * sizeof(double));
     }
-    std::vector<int> hblk;
-    hll_build_blocks(H, off.data(), hblk);
+    // like the CSR stream kernel: larger stages for matrices that have plenty of work
+    const int cap = true_slots >= (16LL << 20) ? kHllCap : kHllCap / 2;
+    std::vector<int4> hdesc;
+    const long long widest = std::max<long long>(2 * kStreamUnit, hll_build_blocks(total_rows, H, off.data(), mz.data(), cap, hdesc));
+    const int stage_slots = (int)std::min<long long>(kHllCap, (widest + kStreamUnit - 1) / kStreamUnit * kStreamUnit);
 
     spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
     if (!m) return fail("hll_upload: out of host memory");
@@ -742,13 +757,14 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
     m->N = N;
     m->hacks = H;
     m->slots = true_slots;
-    m->num_blocks = (int)hblk.size() - 1;
+    m->num_blocks = (int)hdesc.size();
+    m->stage_slots = stage_slots;
     int rc = 0;
     rc |= upload_array(&m->hack_off, off.data(), off.size(), 0);
     if (!rc) rc |= upload_array(&m->maxnz, mz.data(), mz.size(), 1);
     if (!rc) rc |= upload_array(&m->JA, ja.data(), ja.size(), 0);
     if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
-    if (!rc) rc |= upload_array(&m->hblk, hblk.data(), hblk.size(), 0);
+    if (!rc) rc |= upload_array(&m->hdesc, hdesc.data(), hdesc.size(), 1);
     if (!rc) {
         hipError_t e = hipMalloc((void **)&m->x, std::max<size_t>((size_t)N, 1) * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
@@ -760,7 +776,7 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
         spmv_hip_hll_free(m);
         return -1;
     }
-    m->device_bytes = off.size() * 8 + mz.size() * 4 + ja.size() * 4 + as.size() * 8 + hblk.size() * 4 +
+    m->device_bytes = off.size() * 8 + mz.size() * 4 + ja.size() * 4 + as.size() * 8 + hdesc.size() * 16 +
                       ((size_t)N + (size_t)total_rows) * 8;
     const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
     m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
@@ -774,7 +790,7 @@ extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
     (void)hipFree(m->maxnz);
     (void)hipFree(m->JA);
     (void)hipFree(m->AS);
-    (void)hipFree(m->hblk);
+    (void)hipFree(m->hdesc);
     (void)hipFree(m->x);
     (void)hipFree(m->y);
     delete m;
@@ -839,10 +855,19 @@ int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y, h
                 default: launch_hll_vector<32>(m, x, y, s); break;
             }
             break;
-        case SPMV_HLL_LDS:
-            hipLaunchKernelGGL((hll_lds<double, true>), dim3(m->num_blocks), dim3(kBlock), 0, s, m->M,
-                               m->hblk, m->hack_off, m->maxnz, m->JA, m->AS, x, y);
+        case SPMV_HLL_LDS: {
+            const size_t lds = 32 + ((size_t)m->stage_slots + 2) * sizeof(double);
+#define SPMV_HLL_LDS_LAUNCH(MAXU)                                                                  \
+    hipLaunchKernelGGL((hll_lds<double, true, MAXU>), dim3(m->num_blocks), dim3(kBlock), lds, s,    \
+                       m->stage_slots, m->hdesc, m->hack_off, m->maxnz, m->JA, m->AS, x, y)
+            const int units = m->stage_slots / kStreamUnit;
+            if (units <= 2) SPMV_HLL_LDS_LAUNCH(2);
+            else if (units <= 4) SPMV_HLL_LDS_LAUNCH(4);
+            else if (units <= 6) SPMV_HLL_LDS_LAUNCH(6);
+            else SPMV_HLL_LDS_LAUNCH(8);
+#undef SPMV_HLL_LDS_LAUNCH
             break;
+        }
         default:
             return fail("unknown HLL variant %d", variant);
     }
