@@ -322,3 +322,27 @@ def test_powerlaw_fp32_with_many_long_rows(gpu, oracle):
             assert np.max(np.abs(y - y_ref)) <= FP32_NORMWISE_RTOL * scale, vname
         again = dev.spmv(x, sp.CSR_STREAM)
         assert again.tobytes() == dev.spmv(x, sp.CSR_STREAM).tobytes()  # no atomics: reproducible
+
+
+def test_full_size_hll_equals_csr_fem_like(gpu, oracle):
+    """BASELINE config 3's kernel above the Infinity Cache: the FEM-shaped generator at
+    1.23 M rows / 96 M nnz built into HLL by the C host layer; the LDS kernel must agree with
+    the CSR kernel (and with the oracle on a row sample), for x = 1 and a random x."""
+    from sparsematrixvectormultiplication_amd import synth
+    M, row_ptr, col, val = synth.fem_like((40, 40, 257), 1)
+    rows = np.repeat(np.arange(M, dtype=np.int32), np.diff(row_ptr))
+    hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, M, rows, col, val))
+    assert hll.num_blocks == (M + 31) // 32
+    rng = np.random.default_rng(12)
+    with sp.HllDevice(hll) as hdev, sp.CsrDevice(M, M, row_ptr, col, val) as cdev:
+        for x in (np.ones(M), rng.uniform(-1, 1, M)):
+            y_csr = cdev.spmv(x, sp.CSR_STREAM)
+            for variant in (sp.HLL_LDS, sp.HLL_SUBWAVE):
+                y_hll = hdev.spmv(x, variant)
+                scale = np.max(np.abs(y_csr))
+                assert np.max(np.abs(y_hll - y_csr)) <= 1e-12 * scale
+            lo, hi = M // 3, M // 3 + 5000
+            e0, e1 = row_ptr[lo], row_ptr[hi]
+            rp = (row_ptr[lo:hi + 1] - e0).astype(np.int32)
+            ref = oracle.csr_serial(rp, col[e0:e1], val[e0:e1], x)
+            assert_parity(y_hll[lo:hi], ref, rp, col[e0:e1], val[e0:e1], x, what="hll rows sample")
