@@ -67,3 +67,34 @@ def test_bench_row_partitioned_two_ranks_sharing_the_gpu(gpu):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["parallelism"] == "row-block x2"
     assert proc.stderr.count("check: max|y - y_ref|") == 2
+
+
+@pytest.mark.gpu
+def test_native_communicator_under_torch_first_load_order(gpu):
+    """bench.py imports torch before libspmv_amd.so, so the C-ABI's RCCL calls bind to the
+    librccl that torch ships, not /opt/rocm's.  Same single-rank exchange in that load order."""
+    import sys
+    code = r'''
+import numpy as np, torch
+import sparsematrixvectormultiplication_amd as sp
+from sparsematrixvectormultiplication_amd.distributed import NativeComm
+assert torch.cuda.is_available()
+torch.cuda.set_device(0)
+sp.hip_init(0)
+comm = NativeComm(0, 1, lambda ident: ident)
+rp = np.arange(0, 3 * 600 + 1, 3, dtype=np.int32)
+col = (np.arange(1800) * 7 % 600).astype(np.int32)
+col = np.sort(col.reshape(600, 3), axis=1).ravel().astype(np.int32)
+val = np.linspace(-1, 1, 1800)
+with sp.CsrDevice(600, 600, rp, col, val) as dev:
+    dev.set_x(np.ones(600))
+    mk, mx = dev.step_time(np.array([0, 600], np.int32), sp.CSR_AUTO, 1, 3)
+    y = dev.get_y()
+    assert np.allclose(y, val.reshape(600, 3).sum(axis=1)) and mk.shape == (3,)
+comm.close()
+t = torch.ones(4, device="cuda") * 2
+assert float(t.sum()) == 8.0      # torch's own runtime still works next to the library
+print("ok")
+'''
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert proc.returncode == 0 and "ok" in proc.stdout, proc.stderr[-3000:]
