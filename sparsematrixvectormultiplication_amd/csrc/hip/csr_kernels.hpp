@@ -259,10 +259,10 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chun
 
 // ------------------------------------------------------------------- probe
 // Ablation of csr_stream (measurement aid, results are NOT y = A x): what does each
-// phase cost?  MODE bit 0: gather x (else x = 1), bit 2: gather from x[c & 1023], bit 1: LDS stage + row sums (else
+// phase cost?  MODE bit 0: gather x (else x = 1), bit 2: gather from x[c & table_mask], bit 1: LDS stage + row sums (else
 // lanes keep their products and one value per lane-pair is stored).
 template <typename T, bool NT, int CAP, int MODE>
-__global__ __launch_bounds__(kBlock) void csr_probe(int num_blocks, int xcd_chunk,
+__global__ __launch_bounds__(kBlock) void csr_probe(int num_blocks, int xcd_chunk, int table_mask,
                                                     const int4 *__restrict__ desc,
                                                     const int *__restrict__ row_ptr,
                                                     const int *__restrict__ col,
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(kBlock) void csr_probe(int num_blocks, int xcd_chun
 #pragma unroll
     for (int u = 0; u < kUnits; ++u) {
         if (MODE & 4) {  // same instructions, indices folded into an 8 KiB (L1-resident) table
-            xv[2 * u] = gather(x, c[u].x & 1023);
-            xv[2 * u + 1] = gather(x, c[u].y & 1023);
+            xv[2 * u] = gather(x, c[u].x & table_mask);
+            xv[2 * u + 1] = gather(x, c[u].y & table_mask);
         } else if (MODE & 1) {
             xv[2 * u] = gather(x, c[u].x);
             xv[2 * u + 1] = gather(x, c[u].y);

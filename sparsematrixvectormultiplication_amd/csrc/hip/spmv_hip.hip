@@ -42,6 +42,7 @@ int g_stream_xcd = 0;     // blocks per XCD run (xcd_chunked); 0 = dispatch orde
 int g_stream_kind = 0;     // 0 = csr_stream (products), 1 = csr_stream_rows (row walk), 2 = csr_stream_pipe
 int g_pipe_wgs_per_cu = 5; // resident workgroups per CU the persistent grid is sized for
 int g_num_cus = 256;
+int g_probe_mask = 1023;   // csr_probe: table size - 1 (entries) of the folded gather
 
 int fail(const char *fmt, ...) {
     va_list ap;
@@ -213,6 +214,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "stream_xcd")) {
         if (value < -1) return fail("set_tuning: stream_xcd must be -1, 0 or a positive run length");
         g_stream_xcd = value;
+    } else if (!strcmp(key, "probe_mask")) {
+        g_probe_mask = value;
     } else if (!strcmp(key, "stream_kind")) {
         if ((value < 0 || value > 4) && (value < 10 || value > 17))
             return fail("set_tuning: stream_kind must be 0..4 (or 10..17 for the ablation probes)");
@@ -554,7 +557,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     }
                 } else if (g_stream_kind >= 10 && g_stream_kind <= 17 && (cap == 2048 || cap == 4096)) {
                     // ablation probes (measurement only; y is not A x)
-#define SPMV_PROBE(CAP, MODE) hipLaunchKernelGGL((csr_probe<T, true, CAP, MODE>), dim3(grid_blocks), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS)
+#define SPMV_PROBE(CAP, MODE) hipLaunchKernelGGL((csr_probe<T, true, CAP, MODE>), dim3(grid_blocks), dim3(kBlock), 0, s, m->num_blocks, chunk, g_probe_mask, SPMV_ARGS)
                     const int mode = g_stream_kind - 10;
                     if (cap == 2048) { if (mode == 0) SPMV_PROBE(2048, 0); else if (mode == 1) SPMV_PROBE(2048, 1); else if (mode == 2) SPMV_PROBE(2048, 2); else if (mode == 3) SPMV_PROBE(2048, 3); else if (mode == 5) SPMV_PROBE(2048, 5); else SPMV_PROBE(2048, 7); }
                     else { if (mode == 0) SPMV_PROBE(4096, 0); else if (mode == 1) SPMV_PROBE(4096, 1); else if (mode == 2) SPMV_PROBE(4096, 2); else if (mode == 3) SPMV_PROBE(4096, 3); else if (mode == 5) SPMV_PROBE(4096, 5); else SPMV_PROBE(4096, 7); }

@@ -14,10 +14,10 @@ from sparsematrixvectormultiplication_amd.device import set_tuning  # noqa: E402
 
 LAUNCHES = 6
 CONFIGS = []
-for mode, name in ((0, "stream"), (1, "stream+gather"), (5, "stream+gather(L1 table)"), (3, "all"), (7, "all, gather(L1 table)")):
-    CONFIGS.append((f"probe cap=4096 {name}", 4096, dict(stream_kind=10 + mode, stream_xcd=0)))
-CONFIGS.append(("prod cap=4096", 4096, dict(stream_kind=0, stream_xcd=0)))
-CONFIGS.append(("walk cap=4096", 4096, dict(stream_kind=1, stream_xcd=0)))
+CONFIGS.append(("probe stream", 4096, dict(stream_kind=10, stream_xcd=0)))
+CONFIGS.append(("probe stream+gather real x (28 MB)", 4096, dict(stream_kind=11, stream_xcd=0)))
+for mask, nm in ((1023, "8 KiB"), (4095, "32 KiB"), (32767, "256 KiB"), (262143, "2 MiB"), (1048575, "8 MiB"), (2097151, "16 MiB")):
+    CONFIGS.append((f"probe stream+gather table {nm}", 4096, dict(stream_kind=15, stream_xcd=0, probe_mask=mask)))
 
 
 def main():
