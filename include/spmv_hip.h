@@ -139,6 +139,13 @@ int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, int z
 /* ---- HLL --------------------------------------------------------------- */
 /* total_rows = the matrix' M (the last hack may hold fewer than 32 rows). */
 int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out);
+/* build the HLL slab ON THE DEVICE from a resident whole fp64 CSR matrix
+ * (per-hack maximum, H-sized offset scan on the host, fill kernel); same slab as
+ * convert_to_hll + spmv_hip_hll_upload give when no column repeats inside a row. */
+int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out);
+/* flat slab back to the host: hack_off[hacks + 1] (slot offsets, each hack starts on an even
+ * slot), maxnz[hacks], JA / AS [hack_off[hacks]]; any pointer may be NULL */
+int spmv_hip_hll_download(const spmv_hll_dev *m, long long *hack_off, int *maxnz, int *JA, double *AS);
 void spmv_hip_hll_free(spmv_hll_dev *m);
 int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out);
 int spmv_hip_hll_set_x(spmv_hll_dev *m, const double *x_host);

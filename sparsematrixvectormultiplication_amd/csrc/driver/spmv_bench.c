@@ -72,25 +72,33 @@ static int run_gpu(int is_hll, void *dev, int variant, MediumPerformanceMetric s
     return 0;
 }
 
+/* --hll-on-device: HLL is built on the GPU from the resident CSR (spmv_hip_hll_from_csr);
+ * the host builder then only runs when the checker's serial HLL pass needs its blocks */
+static int g_hll_on_device = 0;
+
 static int bench_matrix(const char *path, const char *name, const char *out_dir, int iters,
                         serial_csr_fn serial_csr, serial_hll_fn serial_hll) {
     PreMatrix pre;
     CSRMatrix csr;
     HLLMatrix hll;
+    const int host_hll = !g_hll_on_device || serial_hll != NULL;
+    memset(&hll, 0, sizeof hll);
     if (process_matrix_file(path, &pre) != 0) return -1;
     if (convert_in_csr(&pre, &csr, name) != 0) { free_pre_matrix(&pre); return -1; }
-    if (convert_to_hll(&pre, &hll) != 0) { free_csr_matrix(&csr); free_pre_matrix(&pre); return -1; }
+    if (host_hll && convert_to_hll(&pre, &hll) != 0) { free_csr_matrix(&csr); free_pre_matrix(&pre); return -1; }
     const int M = csr.M, N = csr.N, nz = csr.nz;
+    const size_t padded_rows = (size_t)((M + HACK_SIZE - 1) / HACK_SIZE) * HACK_SIZE + 1;
     double *x = (double *)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
-    double *y_ref = (double *)calloc((size_t)hll.num_blocks * HACK_SIZE + 1, sizeof(double));
+    double *y_ref = (double *)calloc(padded_rows, sizeof(double));
     double *y_gpu = (double *)calloc((size_t)(M > 0 ? M : 1), sizeof(double));
-    double *y_hll = (double *)calloc((size_t)hll.num_blocks * HACK_SIZE + 1, sizeof(double));
+    double *y_hll = (double *)calloc(padded_rows, sizeof(double));
     init_vector_at_one(x, N);
 
     spmv_csr_dev *dcsr = NULL;
     spmv_hll_dev *dhll = NULL;
     int rc = spmv_hip_csr_upload_matrix(&csr, &dcsr) || spmv_hip_csr_set_x(dcsr, x) ||
-             spmv_hip_hll_upload(&hll, M, N, &dhll) || spmv_hip_hll_set_x(dhll, x);
+             (g_hll_on_device ? spmv_hip_hll_from_csr(dcsr, &dhll) : spmv_hip_hll_upload(&hll, M, N, &dhll)) ||
+             spmv_hip_hll_set_x(dhll, x);
     if (rc) {
         fprintf(stderr, "%s: GPU setup failed: %s\n", name, spmv_hip_last_error());
         goto done;
@@ -168,7 +176,7 @@ done:
     spmv_hip_csr_free(dcsr);
     spmv_hip_hll_free(dhll);
     free(x); free(y_ref); free(y_gpu); free(y_hll);
-    free_hll_matrix(&hll);
+    if (host_hll) free_hll_matrix(&hll);
     free_csr_matrix(&csr);
     free_pre_matrix(&pre);
     return rc ? -1 : 0;
@@ -181,10 +189,11 @@ int main(int argc, char **argv) {
         if (!strcmp(argv[i], "--oracle") && i + 1 < argc) oracle = argv[++i];
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_dir = argv[++i];
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--hll-on-device")) g_hll_on_device = 1;
         else target = argv[i];
     }
     if (!target) {
-        fprintf(stderr, "usage: %s [--oracle liboracle_spmv.so] [--out dir] [--iters n] <file.mtx|dir>\n", argv[0]);
+        fprintf(stderr, "usage: %s [--oracle liboracle_spmv.so] [--out dir] [--iters n] [--hll-on-device] <file.mtx|dir>\n", argv[0]);
         return 2;
     }
     serial_csr_fn serial_csr = NULL;

@@ -222,4 +222,44 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
     }
 }
 
+// ------------------------------------------------------ CSR -> HLL on the device
+// the reference builds HLL on the host with one qsort and two mallocs
+// per row / hack (src/hll_matrix.c:37-257) and uploads hack by hack.  With the CSR matrix
+// already resident (columns ascending inside each row, as convert_in_csr leaves them) the
+// flat slab is two trivial kernels: the per-hack maximum row length, then a fill that
+// copies each row and pads it exactly as the host builder does (value 0, column = the
+// row's last real column, 0 for an empty row; src/hll_matrix.c:129-140,241-246).
+__global__ __launch_bounds__(kBlock) void hll_hack_maxnz(int M, int hacks, const int *__restrict__ row_ptr,
+                                                         int *__restrict__ maxnz) {
+    const int h = blockIdx.x * kBlock + threadIdx.x;
+    if (h >= hacks) return;
+    const int r0 = h * kHack, r1 = min(r0 + kHack, M);
+    int m = 0;
+    for (int r = r0; r < r1; ++r) m = max(m, row_ptr[r + 1] - row_ptr[r]);
+    maxnz[h] = m;
+}
+
+// one wavefront per row: lanes stride over the row's maxnz slots
+template <typename T>
+__global__ __launch_bounds__(kBlock) void hll_fill_from_csr(int M, const int *__restrict__ row_ptr,
+                                                            const int *__restrict__ col,
+                                                            const T *__restrict__ val,
+                                                            const long long *__restrict__ hack_off,
+                                                            const int *__restrict__ maxnz,
+                                                            int *__restrict__ JA, T *__restrict__ AS) {
+    const int r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    if (r >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int h = r / kHack;
+    const int m = maxnz[h];
+    const int begin = row_ptr[r], len = row_ptr[r + 1] - begin;
+    const long long at = hack_off[h] + (long long)(r % kHack) * m;
+    const int pad_col = len > 0 ? col[begin + len - 1] : 0;
+    for (int j = lane; j < m; j += 64) {
+        const bool real = j < len;
+        JA[at + j] = real ? col[begin + j] : pad_col;
+        AS[at + j] = real ? val[begin + j] : T(0);
+    }
+}
+
 }  // namespace spmv

@@ -708,19 +708,69 @@ long long hll_build_blocks(int M, int hacks, const long long *off, const int *mz
 
 }  // namespace
 
+namespace {
+
+// offsets of the hacks in the flat slab: every hack starts on an even slot
+long long hll_offsets(int total_rows, const std::vector<int> &mz, std::vector<long long> &off,
+                      long long &true_slots) {
+    const int H = (int)mz.size();
+    off.assign((size_t)H + 1, 0);
+    true_slots = 0;
+    for (int h = 0; h < H; ++h) {
+        const int rows = (h == H - 1) ? total_rows - h * kHack : kHack;
+        const long long s = (long long)rows * mz[h];
+        true_slots += s;
+        off[h + 1] = off[h] + ((s + 1) & ~1LL);
+    }
+    return off[H];
+}
+
+// workgroup windows, small arrays and vectors of a handle whose JA / AS are already on the device
+int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<long long> &off,
+                      const std::vector<int> &mz, long long true_slots, bool upload_maxnz) {
+    const int H = (int)mz.size();
+    // like the CSR stream kernel: larger stages for matrices that have plenty of work
+    const int cap = true_slots >= (16LL << 20) ? kHllCap : kHllCap / 2;
+    std::vector<int4> hdesc;
+    const long long widest =
+        std::max<long long>(2 * kStreamUnit, hll_build_blocks(total_rows, H, off.data(), mz.data(), cap, hdesc));
+    m->M = total_rows;
+    m->N = N;
+    m->hacks = H;
+    m->slots = true_slots;
+    m->num_blocks = (int)hdesc.size();
+    m->stage_slots = (int)std::min<long long>(kHllCap, (widest + kStreamUnit - 1) / kStreamUnit * kStreamUnit);
+    int rc = 0;
+    rc |= upload_array(&m->hack_off, off.data(), off.size(), 0);
+    if (!rc && upload_maxnz) rc |= upload_array(&m->maxnz, mz.data(), mz.size(), 1);
+    if (!rc) rc |= upload_array(&m->hdesc, hdesc.data(), hdesc.size(), 1);
+    if (!rc) {
+        hipError_t e = hipMalloc((void **)&m->x, std::max<size_t>((size_t)N, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(m->x, 0, std::max<size_t>((size_t)N, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
+        if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
+    }
+    m->device_bytes = off.size() * 8 + mz.size() * 4 + ((size_t)off[H] + kPad) * 12 + hdesc.size() * 16 +
+                      ((size_t)N + (size_t)total_rows) * 8;
+    const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
+    m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
+    return rc;
+}
+
+}  // namespace
+
 extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
     if (need_device()) return -1;
     if (!hll || !out) return fail("hll_upload: NULL argument");
     *out = nullptr;
-    const int H = hll->num_blocks;
     if ((unsigned long long)N * 8 >= (1ull << 32))
         return fail("hll_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
+    const int H = hll->num_blocks;
     if (H != (total_rows + kHack - 1) / kHack)
         return fail("hll_upload: %d hacks do not match %d rows", H, total_rows);
 
-    std::vector<long long> off((size_t)H + 1, 0);
     std::vector<int> mz((size_t)H, 0);
-    long long true_slots = 0;
     for (int h = 0; h < H; ++h) {
         const ELLPACKBlock *b = &hll->blocks[h];
         const int expect = (h == H - 1) ? total_rows - h * kHack : kHack;
@@ -732,10 +782,10 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
         for (long long k = 0; k < s; ++k)
             if ((unsigned)b->JA[k] >= (unsigned)N)
                 return fail("hll_upload: column index %d in hack %d is outside [0, %d)", b->JA[k], h, N);
-        true_slots += s;
-        off[h + 1] = off[h] + ((s + 1) & ~1LL);  // next hack starts on an even slot
     }
-    const long long S = off[H];
+    std::vector<long long> off;
+    long long true_slots = 0;
+    const long long S = hll_offsets(total_rows, mz, off, true_slots);
     if (S > (1LL << 40)) return fail("hll_upload: %lld padded slots is unreasonable", S);
 
     // pack every hack into one flat pair of host arrays, then two copies
@@ -748,42 +798,82 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
         memcpy(&ja[(size_t)off[h]], b->JA, s * sizeof(int));
         memcpy(&as[(size_t)off[h]], b->AS, s * sizeof(double));
     }
-    // like the CSR stream kernel: larger stages for matrices that have plenty of work
-    const int cap = true_slots >= (16LL << 20) ? kHllCap : kHllCap / 2;
-    std::vector<int4> hdesc;
-    const long long widest = std::max<long long>(2 * kStreamUnit, hll_build_blocks(total_rows, H, off.data(), mz.data(), cap, hdesc));
-    const int stage_slots = (int)std::min<long long>(kHllCap, (widest + kStreamUnit - 1) / kStreamUnit * kStreamUnit);
-
     spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
     if (!m) return fail("hll_upload: out of host memory");
-    m->M = total_rows;
-    m->N = N;
-    m->hacks = H;
-    m->slots = true_slots;
-    m->num_blocks = (int)hdesc.size();
-    m->stage_slots = stage_slots;
-    int rc = 0;
-    rc |= upload_array(&m->hack_off, off.data(), off.size(), 0);
-    if (!rc) rc |= upload_array(&m->maxnz, mz.data(), mz.size(), 1);
-    if (!rc) rc |= upload_array(&m->JA, ja.data(), ja.size(), 0);
+    int rc = upload_array(&m->JA, ja.data(), ja.size(), 0);
     if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
-    if (!rc) rc |= upload_array(&m->hdesc, hdesc.data(), hdesc.size(), 1);
-    if (!rc) {
-        hipError_t e = hipMalloc((void **)&m->x, std::max<size_t>((size_t)N, 1) * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(m->x, 0, std::max<size_t>((size_t)N, 1) * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
-        if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
-    }
+    if (!rc) rc |= hll_finish_handle(m, total_rows, N, off, mz, true_slots, true);
     if (rc) {
         spmv_hip_hll_free(m);
         return -1;
     }
-    m->device_bytes = off.size() * 8 + mz.size() * 4 + ja.size() * 4 + as.size() * 8 + hdesc.size() * 16 +
-                      ((size_t)N + (size_t)total_rows) * 8;
-    const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
-    m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
     *out = m;
+    return 0;
+}
+
+// HLL built on the device from a resident CSR matrix (whole matrix, fp64).
+extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out) {
+    if (need_device()) return -1;
+    if (!csr || !out) return fail("hll_from_csr: NULL argument");
+    *out = nullptr;
+    if (csr->value_bytes != 8 || csr->row0 != 0 || csr->M_local != csr->M_total)
+        return fail("hll_from_csr: needs a whole fp64 CSR matrix");
+    const int M = csr->M_total, N = csr->N, H = (M + kHack - 1) / kHack;
+    spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
+    if (!m) return fail("hll_from_csr: out of host memory");
+    std::vector<int> mz((size_t)H, 0);
+    std::vector<long long> off;
+    long long true_slots = 0;
+    int rc = 0;
+    do {
+        hipError_t e = hipMalloc((void **)&m->maxnz, ((size_t)H + 1) * sizeof(int));
+        if (e != hipSuccess) { rc = fail("hipMalloc(maxnz) failed: %s", hipGetErrorString(e)); break; }
+        if (H > 0) {
+            hipLaunchKernelGGL(hll_hack_maxnz, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, g_stream, M, H,
+                               csr->row_ptr, m->maxnz);
+            e = hipMemcpyAsync(mz.data(), m->maxnz, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, g_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+            if (e != hipSuccess) { rc = fail("hll_from_csr: maxnz pass failed: %s", hipGetErrorString(e)); break; }
+        }
+        const long long S = hll_offsets(M, mz, off, true_slots);  // H-sized scan on the host
+        if (S > (1LL << 40)) { rc = fail("hll_from_csr: %lld padded slots is unreasonable", S); break; }
+        e = hipMalloc((void **)&m->JA, ((size_t)S + kPad) * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&m->AS, ((size_t)S + kPad) * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(m->JA, 0, ((size_t)S + kPad) * sizeof(int), g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(m->AS, 0, ((size_t)S + kPad) * sizeof(double), g_stream);
+        if (e != hipSuccess) { rc = fail("hll_from_csr: slab allocation failed: %s", hipGetErrorString(e)); break; }
+        rc = hll_finish_handle(m, M, N, off, mz, true_slots, false);
+        if (rc) break;
+        if (M > 0) {
+            hipLaunchKernelGGL((hll_fill_from_csr<double>), dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
+                               0, g_stream, M, csr->row_ptr, csr->col, (const double *)csr->val, m->hack_off,
+                               m->maxnz, m->JA, m->AS);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+            if (e != hipSuccess) { rc = fail("hll_from_csr: fill failed: %s", hipGetErrorString(e)); break; }
+        }
+    } while (0);
+    if (rc) {
+        spmv_hip_hll_free(m);
+        return -1;
+    }
+    *out = m;
+    return 0;
+}
+
+// flat slab back to the host (tests; hosts that want the HLL arrays): hack_off[hacks + 1],
+// maxnz[hacks], JA / AS [hack_off[hacks]]; any pointer may be NULL
+extern "C" int spmv_hip_hll_download(const spmv_hll_dev *m, long long *hack_off, int *maxnz, int *JA, double *AS) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_download: NULL handle");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    std::vector<long long> off((size_t)m->hacks + 1);
+    HIP_TRY(hipMemcpy(off.data(), m->hack_off, off.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    if (hack_off) memcpy(hack_off, off.data(), off.size() * sizeof(long long));
+    if (maxnz && m->hacks) HIP_TRY(hipMemcpy(maxnz, m->maxnz, (size_t)m->hacks * sizeof(int), hipMemcpyDeviceToHost));
+    const size_t S = (size_t)off[m->hacks];
+    if (JA && S) HIP_TRY(hipMemcpy(JA, m->JA, S * sizeof(int), hipMemcpyDeviceToHost));
+    if (AS && S) HIP_TRY(hipMemcpy(AS, m->AS, S * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

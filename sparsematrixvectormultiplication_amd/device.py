@@ -169,11 +169,34 @@ class HllDevice(_Handle):
 
     _free = "spmv_hip_hll_free"
 
-    def __init__(self, hll: HllHost):
+    def __init__(self, hll: HllHost = None):
         super().__init__()
-        _check(nat.lib().spmv_hip_hll_upload(C.byref(hll.c), int(hll.M), int(hll.N),
-                                             C.byref(self.h)), "spmv_hip_hll_upload")
-        self.M, self.N = hll.M, hll.N
+        if hll is not None:
+            _check(nat.lib().spmv_hip_hll_upload(C.byref(hll.c), int(hll.M), int(hll.N),
+                                                 C.byref(self.h)), "spmv_hip_hll_upload")
+            self.M, self.N = hll.M, hll.N
+
+    @classmethod
+    def from_csr_device(cls, csr: "CsrDevice"):
+        """HLL built on the GPU from a resident CSR matrix (spmv_hip_hll_from_csr)."""
+        self = cls()
+        _check(nat.lib().spmv_hip_hll_from_csr(csr.h, C.byref(self.h)), "spmv_hip_hll_from_csr")
+        self.M, self.N = csr.M, csr.N
+        return self
+
+    def download(self):
+        """(hack_off, maxnz, JA, AS) of the flat device slab."""
+        info = self.info()
+        H = info["hacks"]
+        off = np.zeros(H + 1, dtype=np.int64)
+        mz = np.zeros(max(H, 1), dtype=np.int32)
+        _check(nat.lib().spmv_hip_hll_download(self.h, off.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                               mz.ctypes.data_as(nat.c_int_p), None, None), "hll_download")
+        S = int(off[H])
+        ja, as_ = np.zeros(max(S, 1), np.int32), np.zeros(max(S, 1), np.float64)
+        _check(nat.lib().spmv_hip_hll_download(self.h, None, None, ja.ctypes.data_as(nat.c_int_p),
+                                               as_.ctypes.data_as(nat.c_double_p)), "hll_download")
+        return off, mz[:H], ja[:S], as_[:S]
 
     def info(self) -> dict:
         out = nat.DevInfo()

@@ -34,6 +34,14 @@ def test_c_driver_runs_reference_protocol_on_golden_matrices(tmp_path, gpu):
     subprocess.run([DRIVER, "--out", str(out), "--iters", "6", os.path.join(GOLDEN, "general_matrix.mtx")],
                    check=True, capture_output=True, timeout=120)
     assert len(list(csv.DictReader(open(out / "spmv_results_hip.csv")))) == len(rows) + 1
+    # --hll-on-device: HLL built by the GPU from the resident CSR, same checks
+    out2 = tmp_path / "result_dev"
+    proc = subprocess.run([DRIVER, "--oracle", ORACLE, "--out", str(out2), "--iters", "6", "--hll-on-device",
+                           GOLDEN], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    for r in csv.DictReader(open(out2 / "spmv_results_hip.csv")):
+        for key in ("relative_error_row_hll", "relative_error_warp_hll", "relative_error_warp_shared_hll"):
+            assert float(r[key]) < 1e-10, (r["matrix_name"], key, r[key])
 
 
 def test_c_driver_fails_loudly_without_a_gpu(tmp_path):

@@ -346,3 +346,84 @@ def test_full_size_hll_equals_csr_fem_like(gpu, oracle):
             rp = (row_ptr[lo:hi + 1] - e0).astype(np.int32)
             ref = oracle.csr_serial(rp, col[e0:e1], val[e0:e1], x)
             assert_parity(y_hll[lo:hi], ref, rp, col[e0:e1], val[e0:e1], x, what="hll rows sample")
+        # N1 at full size: the slab built on the GPU from the resident CSR is the host builder's
+        with sp.HllDevice.from_csr_device(cdev) as built:
+            assert built.info()["slots"] == hll.slots
+            a, b = built.download(), hdev.download()
+            for got, want in zip(a, b):
+                assert got.tobytes() == want.tobytes()
+            assert built.spmv(x, sp.HLL_LDS).tobytes() == hdev.spmv(x, sp.HLL_LDS).tobytes()
+
+
+# ------------------------------------------- HLL built on the device (N1)
+def _host_slab(hll):
+    """The flat slab spmv_hip_hll_upload packs: hacks back to back, each on an even slot."""
+    off, ja, as_ = [0], [], []
+    for b in range(hll.num_blocks):
+        rows, mz, j, a = hll.block(b)
+        s = rows * mz
+        pad = s & 1
+        ja.append(np.concatenate([j, np.zeros(pad, np.int32)]))
+        as_.append(np.concatenate([a, np.zeros(pad)]))
+        off.append(off[-1] + s + pad)
+    cat = lambda parts, dt: np.concatenate(parts).astype(dt) if parts else np.zeros(0, dt)
+    return np.array(off, np.int64), cat(ja, np.int32), cat(as_, np.float64)
+
+
+def _check_device_built_hll(pre, csr, x, y_ref, what):
+    hll = sp.convert_to_hll(pre)
+    off_h, ja_h, as_h = _host_slab(hll)
+    with sp.CsrDevice.from_host(csr) as cdev, sp.HllDevice.from_csr_device(cdev) as hdev:
+        info = hdev.info()
+        assert info["hacks"] == hll.num_blocks and info["slots"] == hll.slots, what
+        off, mz, ja, as_ = hdev.download()
+        assert np.array_equal(mz, hll.maxnz), what
+        assert np.array_equal(off, off_h), what
+        assert ja.tobytes() == ja_h.tobytes(), f"{what}: JA differs from convert_to_hll"
+        assert as_.tobytes() == as_h.tobytes(), f"{what}: AS differs from convert_to_hll"
+        with sp.HllDevice(hll) as href:     # same slab -> same bits out of the same kernel
+            for vname, variant in HLL_V:
+                y = hdev.spmv(x, variant)
+                assert y.tobytes() == href.spmv(x, variant).tobytes(), f"{what}/{vname}"
+                assert_parity(y, y_ref, csr.row_ptr, csr.col_idx, csr.values, x, what=f"{what}/{vname}")
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_hll_built_on_device_equals_host_builder_golden(gpu, name):
+    g = load_golden(name)
+    pre = sp.read_matrix_market(golden_path(name))
+    csr = sp.convert_in_csr(pre)
+    lens = np.diff(csr.row_ptr)
+    dup = any(len(np.unique(csr.col_idx[s:s + n])) != n for s, n in zip(csr.row_ptr[:-1], lens))
+    if dup:
+        # a repeated column: CSR keeps the reference quicksort's tie order, HLL the stable
+        # file order (src/hll_matrix.c:14-21), so only the result is comparable
+        with sp.CsrDevice.from_host(csr) as cdev, sp.HllDevice.from_csr_device(cdev) as hdev:
+            assert_parity(hdev.spmv(g["x_rand"]), g["y_rand"], csr.row_ptr, csr.col_idx, csr.values,
+                          g["x_rand"], what=f"{name}/device-hll")
+        return
+    _check_device_built_hll(pre, csr, g["x_rand"], g["y_rand"], name)
+
+
+def test_hll_built_on_device_seeded(gpu, oracle):
+    rng = np.random.default_rng(77)
+    for M, N, mean, mx, empty in [(1, 5, 2, 2, 0.0), (31, 40, 3, 7, 0.5), (32, 32, 5, 9, 0.0),
+                                  (33, 64, 6, 12, 0.1), (1000, 900, 27, 90, 0.05),
+                                  (70, 6000, 100, 1500, 0.0), (4097, 4097, 1, 3, 0.6)]:
+        row_ptr, col, val = random_csr(rng, M, N, mean, mx, empty)
+        r, c, v = coo_from_csr(row_ptr, col, val, rng)
+        pre = sp.PreMatrix.from_arrays(M, N, r, c, v)
+        csr = sp.convert_in_csr(pre)
+        x = rng.uniform(-1, 1, N)
+        _check_device_built_hll(pre, csr, x, oracle.csr_serial(row_ptr, col, val, x), f"{M}x{N}")
+
+
+def test_hll_from_csr_rejects_row_blocks_and_fp32(gpu):
+    rng = np.random.default_rng(5)
+    row_ptr, col, val = random_csr(rng, 200, 200, 5, 9, 0.0)
+    with sp.CsrDevice(200, 200, row_ptr, col, val, row0=50, row1=150) as part:
+        with pytest.raises(RuntimeError, match="whole fp64"):
+            sp.HllDevice.from_csr_device(part)
+    with sp.CsrDevice(200, 200, row_ptr, col, val.astype(np.float32)) as f32:
+        with pytest.raises(RuntimeError, match="whole fp64"):
+            sp.HllDevice.from_csr_device(f32)
