@@ -73,6 +73,9 @@ _PROTOTYPES = {
     "init_csr_matrix": (None, [C.POINTER(CSRMatrix)]),
     "free_csr_matrix": (None, [C.POINTER(CSRMatrix)]),
     "convert_in_csr": (C.c_int, [C.POINTER(PreMatrix), C.POINTER(CSRMatrix), C.c_char_p]),
+    "save_csr_binary": (C.c_int, [C.POINTER(CSRMatrix), C.c_char_p, C.c_char_p]),
+    "load_csr_binary": (C.c_int, [C.c_char_p, C.POINTER(CSRMatrix), C.c_char_p]),
+    "load_csr_cached": (C.c_int, [C.c_char_p, C.POINTER(CSRMatrix), C.POINTER(C.c_int)]),
     "print_csr_matrix": (None, [C.POINTER(CSRMatrix)]),
     "write_memory_stats_to_csv": (None, [C.c_char_p, C.c_int, C.c_size_t]),
     "prepare_thread_distribution": (C.c_int, [C.c_int, c_int_p, C.c_int, C.c_longlong,

@@ -29,6 +29,7 @@
 
 #include "csr_matrix.h"
 #include "hll_matrix.h"
+#include "csr_cache.h"
 #include "matrix_parser.h"
 #include "performance_calculate.h"
 #include "spmv_hip.h"
@@ -75,6 +76,8 @@ static int run_gpu(int is_hll, void *dev, int variant, MediumPerformanceMetric s
 /* --hll-on-device: HLL is built on the GPU from the resident CSR (spmv_hip_hll_from_csr);
  * the host builder then only runs when the checker's serial HLL pass needs its blocks */
 static int g_hll_on_device = 0;
+/* --cache: with --hll-on-device and no --oracle, CSR comes from "<file>.csrbin" when fresh */
+static int g_cache = 0;
 
 static int bench_matrix(const char *path, const char *name, const char *out_dir, int iters,
                         serial_csr_fn serial_csr, serial_hll_fn serial_hll) {
@@ -83,8 +86,16 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
     HLLMatrix hll;
     const int host_hll = !g_hll_on_device || serial_hll != NULL;
     memset(&hll, 0, sizeof hll);
-    if (process_matrix_file(path, &pre) != 0) return -1;
-    if (convert_in_csr(&pre, &csr, name) != 0) { free_pre_matrix(&pre); return -1; }
+    init_pre_matrix(&pre);
+    if (g_cache && !host_hll) {
+        /* nothing downstream needs the COO triplets: take the built CSR from its sidecar */
+        int hit = 0;
+        if (load_csr_cached(path, &csr, &hit) != 0) return -1;
+        printf("%s: CSR %s\n", name, hit ? "read from the .csrbin sidecar" : "parsed and built (sidecar written)");
+    } else {
+        if (process_matrix_file(path, &pre) != 0) return -1;
+        if (convert_in_csr(&pre, &csr, name) != 0) { free_pre_matrix(&pre); return -1; }
+    }
     if (host_hll && convert_to_hll(&pre, &hll) != 0) { free_csr_matrix(&csr); free_pre_matrix(&pre); return -1; }
     const int M = csr.M, N = csr.N, nz = csr.nz;
     const size_t padded_rows = (size_t)((M + HACK_SIZE - 1) / HACK_SIZE) * HACK_SIZE + 1;
@@ -190,10 +201,11 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_dir = argv[++i];
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--hll-on-device")) g_hll_on_device = 1;
+        else if (!strcmp(argv[i], "--cache")) g_cache = 1;
         else target = argv[i];
     }
     if (!target) {
-        fprintf(stderr, "usage: %s [--oracle liboracle_spmv.so] [--out dir] [--iters n] [--hll-on-device] <file.mtx|dir>\n", argv[0]);
+        fprintf(stderr, "usage: %s [--oracle liboracle_spmv.so] [--out dir] [--iters n] [--hll-on-device] [--cache] <file.mtx|dir>\n", argv[0]);
         return 2;
     }
     serial_csr_fn serial_csr = NULL;

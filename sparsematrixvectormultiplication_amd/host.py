@@ -131,6 +131,30 @@ def convert_in_csr(pre: PreMatrix, matrix_name: str = "") -> CsrHost:
     return CsrHost(s, owned_by_c=True)
 
 
+def save_csr_binary(csr: CsrHost, path: str, source_mtx: str = None) -> None:
+    """Binary sidecar of a built CSR matrix (include/csr_cache.h)."""
+    src = source_mtx.encode() if source_mtx else None
+    if nat.lib().save_csr_binary(C.byref(csr.c), str(path).encode(), src) != 0:
+        raise OSError(f"save_csr_binary({path}) failed (-1)")
+
+
+def load_csr_binary(path: str, source_mtx: str = None) -> CsrHost:
+    s = nat.CSRMatrix()
+    src = source_mtx.encode() if source_mtx else None
+    if nat.lib().load_csr_binary(str(path).encode(), C.byref(s), src) != 0:
+        raise ValueError(f"load_csr_binary({path}): missing, stale or damaged sidecar (-1)")
+    return CsrHost(s, owned_by_c=True)
+
+
+def load_csr_cached(mtx_path: str):
+    """(CsrHost, from_cache): "<mtx>.csrbin" when valid and fresh, else parse + build + write it."""
+    s = nat.CSRMatrix()
+    hit = C.c_int(0)
+    if nat.lib().load_csr_cached(str(mtx_path).encode(), C.byref(s), C.byref(hit)) != 0:
+        raise ValueError(f"load_csr_cached({mtx_path}) failed (-1)")
+    return CsrHost(s, owned_by_c=True), bool(hit.value)
+
+
 class HllHost:
     """Host HLL (reference HLLMatrix / ELLPACKBlock, libs/hll_matrix.h:15-27)."""
 
