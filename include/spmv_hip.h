@@ -74,6 +74,12 @@ typedef struct {
     int hacks;             /* HLL only: number of hacks                         */
     long long algo_bytes;  /* algorithmic HBM bytes of one SpMV  */
     long long device_bytes;/* HBM held by the handle                            */
+    int local_blocks;      /* CSR: workgroups of the x-window stream kernel, 0 = matrix has no plan */
+    int local_stage_lines; /* CSR: x lines (128 B) its widest block stages in LDS */
+    long long local_lines; /* CSR: x lines listed over all blocks                 */
+    long long stream_bytes;/* CSR: bytes the x-window kernel really streams from HBM:
+                              nz (val + 2) + 4 lines + 24 blocks + 4 (M + 1) + val (M + N);
+                              0 without a plan (then algo_bytes is what moves)    */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */

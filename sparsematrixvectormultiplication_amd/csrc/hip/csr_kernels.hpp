@@ -257,6 +257,146 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chun
     sum_rows_from_lds<T, BLOCK>(prod, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);
 }
 
+// --------------------------------------------------------- stream, local x
+// csr_stream pays for its gathers in the texture addresser: a 64-lane gather over a
+// stencil-like row touches 16-28 different 128-byte lines of x and occupies the address
+// path for ~60 cycles (profiles/r1_ubench_gather_cost.txt), which on the nlpkkt-like matrix
+// adds up to about as much time as the HBM stream itself.  Yet the x lines one block needs
+// are few: ~75 neighbouring stencil rows share their 28 column offsets, so 2048 entries
+// touch only ~160 lines.  Upload therefore writes, per block, the sorted list of the x lines
+// it touches and replaces each 32-bit column by a 16-bit slot in that list
+// (rank * elements-per-line + column % elements-per-line).  The kernel copies the listed
+// lines into LDS with full-width coalesced loads (8 lines per wave instruction instead of
+// 16-28 lines for a quarter of the payload) and gathers from LDS.  HBM traffic drops too:
+// 2 bytes of index per entry instead of 4, plus 4 bytes per listed line.
+//
+// x must be 128-byte aligned: whole lines are read, the tail of the last one may lie behind
+// x[N - 1] (inside the same aligned line, hence inside the allocation's last page).
+constexpr int kLineBytes = 128;
+constexpr int kLocalLinesMax = 256;  // lines per block: rank fits the 16-bit slot for fp64 and fp32
+constexpr int kLocalLineQuantum = kBlock / 8;  // lines one pass of the workgroup stages (16 B per lane)
+
+template <typename T, bool NT, int CAP, int ROUNDS>
+__device__ __forceinline__ void local_stage_full(T *stage, const int *__restrict__ my_lines, int last_line,
+                                                 const unsigned short *__restrict__ lcol,
+                                                 const T *__restrict__ val, const T *__restrict__ x,
+                                                 int e_first) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
+    const int t = threadIdx.x;
+    // the line list first: the x loads depend on it, and loads come back in issue order
+    int line[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        // lanes behind the end of the list repeat its last line: one more hit on a line that is
+        // being fetched anyway instead of up to 31 extra lines
+        const int at = k * kLocalLineQuantum + (t >> 3);
+        line[k] = stream_load<NT>(my_lines + (k == ROUNDS - 1 ? min(at, last_line) : at));
+    }
+    unsigned c[kUnits];
+    V2 v[kUnits];
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        c[u] = stream_load<NT>(reinterpret_cast<const unsigned *>(lcol + e_first + u * kUnit));
+        v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+    }
+    // keep the HBM stream ahead of the wait for the list (the scheduler would otherwise sink
+    // the value loads behind the x loads, i.e. behind one full memory latency)
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 xl[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const unsigned off = (unsigned)line[k] * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+        xl[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+    }
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k)
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) = xl[k];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        v[u].x *= stage[c[u] & 0xffffu];
+        v[u].y *= stage[c[u] >> 16];
+    }
+    __syncthreads();  // the products take the place of the staged lines
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = v[u];
+}
+
+template <typename T, bool NT, int CAP>
+__global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int xcd_chunk,
+                                                           const int4 *__restrict__ desc,
+                                                           const int2 *__restrict__ ldesc,
+                                                           const int *__restrict__ lines,
+                                                           const int *__restrict__ row_ptr,
+                                                           const unsigned short *__restrict__ lcol,
+                                                           const T *__restrict__ val,
+                                                           const T *__restrict__ x, T *__restrict__ y) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
+    // one LDS stage, used twice: first the x lines of the block, then (after every lane has
+    // gathered its x values into registers) the CAP products.  max(CAP values, staged lines).
+    extern __shared__ __attribute__((aligned(16))) unsigned char local_smem[];
+    T *stage = reinterpret_cast<T *>(local_smem);
+
+    const int b = xcd_chunked(blockIdx.x, xcd_chunk);
+    if (b >= num_blocks) return;
+    const int t = threadIdx.x;
+    const int4 d = desc[b];
+    const int2 ld = ldesc[b];
+    const int r0 = d.x, nrows = d.z;
+    const int base = d.y & kBaseMask;
+
+    const int lanes = lanes_for_rows<kBlock>(nrows);
+    int seg_lo = 0, seg_hi = 0;
+    if (t / lanes < nrows) {
+        seg_lo = row_ptr[r0 + t / lanes];
+        seg_hi = row_ptr[r0 + t / lanes + 1];
+    }
+
+    const int e_first = base + 2 * t;
+    const int units = (d.w - base + kUnit - 1) / kUnit;                       // wave-uniform
+    const int rounds = (ld.y + kLocalLineQuantum - 1) / kLocalLineQuantum;    // wave-uniform, 1..8
+    const int *my_lines = lines + ld.x;
+    if (units == kUnits) {
+        switch (rounds) {
+            case 1: local_stage_full<T, NT, CAP, 1>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            case 2: local_stage_full<T, NT, CAP, 2>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            case 3: local_stage_full<T, NT, CAP, 3>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            case 4: local_stage_full<T, NT, CAP, 4>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            case 5: local_stage_full<T, NT, CAP, 5>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            case 6: local_stage_full<T, NT, CAP, 6>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            case 7: local_stage_full<T, NT, CAP, 7>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            default: local_stage_full<T, NT, CAP, 8>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+        }
+    } else {
+        // a block cut short (row cap, line cap, end of the matrix): plain loops
+        for (int k = 0; k < rounds; ++k) {
+            const int line = my_lines[min(k * kLocalLineQuantum + (t >> 3), ld.y - 1)];
+            const unsigned off = (unsigned)line * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) =
+                *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+        }
+        __syncthreads();
+        V2 p[kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            if (u < units) {
+                const unsigned c = stream_load<NT>(reinterpret_cast<const unsigned *>(lcol + e_first + u * kUnit));
+                p[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+                p[u].x *= stage[c & 0xffffu];
+                p[u].y *= stage[c >> 16];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u)
+            if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = p[u];
+    }
+    __syncthreads();
+    sum_rows_from_lds<T, kBlock>(stage, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);
+}
+
 // ------------------------------------------------------------------- probe
 // Ablation of csr_stream (measurement aid, results are NOT y = A x): what does each
 // phase cost?  MODE bit 0: gather x (else x = 1), bit 2: gather from x[c & table_mask], bit 1: LDS stage + row sums (else

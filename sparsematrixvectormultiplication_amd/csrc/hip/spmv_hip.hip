@@ -39,7 +39,9 @@ int g_stream_cap = 0;     // nnz staged per stream workgroup (fixed at upload); 
 int g_stream_block = 256; // threads per csr_stream workgroup
 int g_stream_nt = 1;      // non-temporal loads for col/val
 int g_stream_xcd = 0;     // blocks per XCD run (xcd_chunked); 0 = dispatch order, -1 = one contiguous eighth per XCD
-int g_stream_kind = 0;     // 0 = csr_stream (products), 1 = csr_stream_rows (row walk), 2 = csr_stream_pipe
+int g_stream_local = 1;    // build the x-window plan at upload (csr_stream_local) when it pays
+int g_stream_kind = -1;    // -1 = auto (csr_stream_local when the matrix has a plan, else csr_stream), 5 = local,
+                           // 0 = csr_stream (products), 1 = csr_stream_rows (row walk), 2 = csr_stream_pipe
 int g_pipe_wgs_per_cu = 5; // resident workgroups per CU the persistent grid is sized for
 int g_num_cus = 256;
 int g_probe_mask = 1023;   // csr_probe: table size - 1 (entries) of the folded gather
@@ -112,6 +114,15 @@ struct spmv_csr_dev {
     int num_partial = 0;
     int stream_cap = 2048;
     bool ring_ok = false;  // blocks respect the ring kernel's row limit
+    // stream kernel with the x window in LDS (csr_stream_local): own blocks, 16-bit local columns
+    int4 *ldesc4 = nullptr;           // [local_blocks] like desc
+    int2 *ldesc = nullptr;            // [local_blocks] {first line in `lines`, line count}
+    int *lines = nullptr;             // x line ids, block after block, ascending inside a block
+    unsigned short *lcol = nullptr;   // [nz + pad] slot of each entry in its block's staged lines
+    int local_blocks = 0;             // 0: no plan (not profitable / not possible)
+    int local_stage_lines = 0;        // LDS stage: most lines any block lists, in steps of 32
+    int local_cap = 2048;
+    long long local_lines = 0;
     // heuristics
     int lanes_per_row = 16;
     int auto_variant = SPMV_CSR_STREAM;
@@ -217,9 +228,11 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "probe_mask")) {
         g_probe_mask = value;
     } else if (!strcmp(key, "stream_kind")) {
-        if ((value < 0 || value > 4) && (value < 10 || value > 17))
-            return fail("set_tuning: stream_kind must be 0..4 (or 10..17 for the ablation probes)");
+        if ((value < -1 || value > 5) && (value < 10 || value > 17))
+            return fail("set_tuning: stream_kind must be -1..5 (or 10..17 for the ablation probes)");
         g_stream_kind = value;
+    } else if (!strcmp(key, "stream_local")) {
+        g_stream_local = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "pipe_wgs_per_cu")) {
         if (value < 1 || value > 8) return fail("set_tuning: pipe_wgs_per_cu must be 1..8");
         g_pipe_wgs_per_cu = value;
@@ -328,6 +341,83 @@ void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<i
     }
 }
 
+// Blocks for csr_stream_local: csr_build_blocks' cut with one more limit, the number of
+// distinct x lines (1 << line_shift elements each) a block touches.  Fills, per block, the
+// ascending list of those lines and, per entry, its 16-bit slot (rank of its line in the
+// list * elements per line + column % elements per line).  Returns false when some row alone
+// needs more than lines_max lines, or when the line limit (rather than cap) decides so many
+// cuts that the blocks would run mostly empty: the caller then keeps the gather kernel.
+struct LocalPlan {
+    std::vector<int4> desc;
+    std::vector<int2> ldesc;
+    std::vector<int> lines;
+    std::vector<unsigned short> lcol;
+    int stage_lines = 0;
+};
+
+bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, int cap, int rows_cap,
+                     int line_shift, int lines_max, const std::vector<int4> &baseline, LocalPlan &plan) {
+    const int total_lines = (int)(((long long)N + (1 << line_shift) - 1) >> line_shift);
+    const int line_mask = (1 << line_shift) - 1;
+    std::vector<int> stamp((size_t)total_lines + 1, -1), rank((size_t)total_lines + 1, 0), cur;
+    plan.lcol.assign((size_t)nz + kPad, 0);
+    plan.desc.clear();
+    plan.ldesc.clear();
+    plan.lines.clear();
+    int widest = 0;
+    int r = 0;
+    while (r < M) {
+        const int n0 = rp[r];
+        const int base = n0 & kBaseMask;
+        if (rp[r + 1] - n0 > cap - 3) {  // long row: csr_long_pieces, as in csr_build_blocks
+            ++r;
+            continue;
+        }
+        const int blk = (int)plan.desc.size();
+        cur.clear();
+        int r1 = r;
+        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && rp[r1 + 1] - rp[r1] <= cap - 3) {
+            const size_t before = cur.size();
+            for (int e = rp[r1]; e < rp[r1 + 1]; ++e) {
+                const int l = col[e] >> line_shift;
+                if (stamp[l] != blk) {
+                    stamp[l] = blk;
+                    cur.push_back(l);
+                }
+            }
+            if ((int)cur.size() > lines_max) {  // this row does not fit any more: take it back
+                for (size_t k = before; k < cur.size(); ++k) stamp[cur[k]] = -1;
+                cur.resize(before);
+                break;
+            }
+            ++r1;
+        }
+        if (r1 == r) return false;  // one row alone touches more lines than a block may list
+        std::sort(cur.begin(), cur.end());
+        for (size_t k = 0; k < cur.size(); ++k) rank[cur[k]] = (int)k;
+        for (int e = rp[r]; e < rp[r1]; ++e)
+            plan.lcol[e] = (unsigned short)((rank[col[e] >> line_shift] << line_shift) | (col[e] & line_mask));
+        plan.desc.push_back(int4{r, n0, r1 - r, rp[r1]});
+        plan.ldesc.push_back(int2{(int)plan.lines.size(), (int)cur.size()});
+        plan.lines.insert(plan.lines.end(), cur.begin(), cur.end());
+        widest = std::max(widest, (int)cur.size());
+        r = r1;
+        // the line limit is cutting blocks well short of what cap alone allows: give up early
+        if ((plan.desc.size() & 1023) == 0) {
+            const size_t plain = std::lower_bound(baseline.begin(), baseline.end(), r,
+                                                  [](const int4 &d, int row) { return d.x < row; }) -
+                                 baseline.begin();
+            if (plan.desc.size() > plain + plain / 5 + 16) return false;
+        }
+    }
+    if (plan.desc.size() > baseline.size() + baseline.size() / 5 + 1) return false;
+    // the kernel stages whole passes of kLocalLineQuantum lines and reads the list unconditionally
+    plan.stage_lines = std::max(kLocalLineQuantum,
+                                (widest + kLocalLineQuantum - 1) / kLocalLineQuantum * kLocalLineQuantum);
+    plan.lines.insert(plan.lines.end(), (size_t)kLocalLinesMax, 0);
+    return true;
+}
+
 template <typename T>
 int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const T *values, int row0,
                     int row1, spmv_csr_dev **out) {
@@ -383,8 +473,32 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     m->num_partial = (int)pieces.size();
     const int num_partial = m->num_partial;
 
+    // the x-window kernel: own blocks (cap 2048: LDS holds products AND the staged lines)
+    LocalPlan local;
+    bool have_local = false;
+    if (g_stream_local && nz > 0) {
+        std::vector<int4> base_desc, p2, l2;
+        m->local_cap = 2048;
+        if (m->stream_cap == m->local_cap && !m->ring_ok) base_desc = desc;
+        else csr_build_blocks(Ml, rp.data(), m->local_cap, kStreamRowsCap, base_desc, p2, l2);
+        constexpr int line_shift = sizeof(T) == 8 ? 4 : 5;  // 128-byte lines
+        have_local = csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, m->local_cap, kStreamRowsCap, line_shift,
+                                     kLocalLinesMax, base_desc, local);
+    }
+
     int rc = 0;
     rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), (size_t)kRingRows + 64);
+    if (!rc && have_local) {
+        rc |= upload_array(&m->ldesc4, local.desc.data(), local.desc.size(), 1);
+        if (!rc) rc |= upload_array(&m->ldesc, local.ldesc.data(), local.ldesc.size(), 1);
+        if (!rc) rc |= upload_array(&m->lines, local.lines.data(), local.lines.size(), 0);
+        if (!rc) rc |= upload_array(&m->lcol, local.lcol.data(), local.lcol.size(), 0);
+        if (!rc) {
+            m->local_blocks = (int)local.desc.size();
+            m->local_stage_lines = local.stage_lines;
+            m->local_lines = (long long)local.lines.size() - kLocalLinesMax;
+        }
+    }
     if (!rc) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
@@ -395,9 +509,11 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
         if (e != hipSuccess) rc = fail("hipMalloc(partial) failed: %s", hipGetErrorString(e));
     }
     if (!rc) {
-        hipError_t e = hipMalloc(&m->x, std::max<size_t>((size_t)N, 1) * sizeof(T));
+        // x is read in whole 128-byte lines by csr_stream_local: room for the tail of the last one
+        const size_t x_bytes = std::max<size_t>((size_t)N, 1) * sizeof(T) + kLineBytes;
+        hipError_t e = hipMalloc(&m->x, x_bytes);
         if (e == hipSuccess) e = hipMalloc(&m->y, std::max<size_t>((size_t)M, 1) * sizeof(T));
-        if (e == hipSuccess) e = hipMemset(m->x, 0, std::max<size_t>((size_t)N, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMemset(m->x, 0, x_bytes);
         if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)M, 1) * sizeof(T));
         if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
     }
@@ -408,6 +524,8 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     m->device_bytes = rp.size() * 4 + ((size_t)nz + kPad) * (4 + sizeof(T)) + desc.size() * 16 +
                       long_rows.size() * 16 + pieces.size() * 16 + (size_t)num_partial * sizeof(T) +
                       ((size_t)N + (size_t)M) * sizeof(T);
+    if (have_local)
+        m->device_bytes += local.desc.size() * 24 + local.lines.size() * 4 + local.lcol.size() * 2;
 
     // lanes per row for the SUBWAVE kernel: about half the mean row length,
     // rounded to a power of two, so that a typical row takes 1-2 passes
@@ -442,6 +560,10 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->col);
     (void)hipFree(m->val);
     (void)hipFree(m->desc);
+    (void)hipFree(m->ldesc4);
+    (void)hipFree(m->ldesc);
+    (void)hipFree(m->lines);
+    (void)hipFree(m->lcol);
     (void)hipFree(m->long_rows);
     (void)hipFree(m->pieces);
     (void)hipFree(m->partial);
@@ -467,6 +589,12 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     // nnz (val + 4) + 4 (M + 1) + val M [y] + val N [x]
     out->algo_bytes = m->nz * (vb + 4) + 4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
     out->device_bytes = (long long)m->device_bytes;
+    out->local_blocks = m->local_blocks;
+    out->local_stage_lines = m->local_stage_lines;
+    out->local_lines = m->local_lines;
+    if (m->local_blocks > 0)
+        out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
+                            4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
     return 0;
 }
 
@@ -545,7 +673,25 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                 const int grid_blocks = chunk > 0 ? (m->num_blocks + 8 * chunk - 1) / (8 * chunk) * (8 * chunk)
                                                   : m->num_blocks;
                 const int cap = m->stream_cap, blk = g_stream_block;
-                if (g_stream_kind == 4 && m->ring_ok) {
+                // the x-window kernel reads whole aligned lines of x
+                const bool local = (g_stream_kind == -1 || g_stream_kind == 5) && m->local_blocks > 0 &&
+                                   ((uintptr_t)x & (kLineBytes - 1)) == 0;
+                if (local) {
+                    // runs of 16 neighbouring blocks per XCD: each L2 keeps its own window of x lines
+                    // (measured flat from 8 to 128 on three matrices); stream_xcd overrides
+                    const int lchunk = g_stream_xcd < 0 ? (m->local_blocks + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
+                    const int lgrid = lchunk > 0 ? (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk)
+                                                 : m->local_blocks;
+                    const size_t lds = std::max((size_t)m->local_cap * sizeof(T), (size_t)m->local_stage_lines * kLineBytes);
+                    if (g_stream_nt)
+                        hipLaunchKernelGGL((csr_stream_local<T, true, 2048>), dim3(lgrid), dim3(kBlock), lds, s,
+                                           m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_ptr,
+                                           m->lcol, (const T *)m->val, x, y);
+                    else
+                        hipLaunchKernelGGL((csr_stream_local<T, false, 2048>), dim3(lgrid), dim3(kBlock), lds, s,
+                                           m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_ptr,
+                                           m->lcol, (const T *)m->val, x, y);
+                } else if (g_stream_kind == 4 && m->ring_ok) {
                     // loader / consumer ring: one persistent 512-thread workgroup per CU
                     const int wgs = std::max(1, std::min(g_num_cus * g_pipe_wgs_per_cu, m->num_blocks));
                     if (g_pipe_wgs_per_cu >= 2) {

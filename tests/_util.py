@@ -62,3 +62,29 @@ def coo_from_csr(row_ptr, col, val, rng=None):
         order = rng.permutation(len(rows))
         return rows[order], col[order], val[order]
     return rows, col, val
+
+
+def banded_csr(rng, M, N, mean_row, band, empty_frac=0.0, dtype=np.float64, far_frac=0.0):
+    """Random CSR whose columns stay within `band` of the diagonal (plus, for far_frac of the
+    rows, one cluster far away), sorted and distinct per row: few x lines per row block."""
+    lens = np.minimum(rng.poisson(mean_row, M), min(N, 2 * band)).astype(np.int64)
+    lens[rng.random(M) < empty_frac] = 0
+    row_ptr = np.zeros(M + 1, dtype=np.int32)
+    np.cumsum(lens, out=row_ptr[1:])
+    col = np.empty(row_ptr[-1], dtype=np.int32)
+    for r in range(M):
+        n = lens[r]
+        if not n:
+            continue
+        centre = int(r * (N - 1) / max(M - 1, 1))
+        lo = max(0, min(centre - band, N - 2 * band))
+        cand = np.arange(lo, min(N, lo + 2 * band))
+        c = rng.choice(cand, n, replace=False)
+        if far_frac and rng.random() < far_frac:
+            k = max(1, n // 4)
+            c[:k] = (c[:k] + N // 2) % N
+            c = np.unique(c)
+            c = np.concatenate([c, rng.choice(np.setdiff1d(cand, c), n - len(c), replace=False)]) if len(c) < n else c
+        col[row_ptr[r]:row_ptr[r + 1]] = np.sort(c)
+    val = rng.uniform(-1, 1, row_ptr[-1]).astype(dtype)
+    return row_ptr, col, val

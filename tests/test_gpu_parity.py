@@ -116,7 +116,7 @@ def test_stream_kernel_block_shapes_repeatable(gpu, oracle, mean, dtype):
                         assert y.tobytes() == first.tobytes(), "result changed between launches"
     finally:
         set_tuning("stream_cap", 0)
-        set_tuning("stream_kind", 0)
+        set_tuning("stream_kind", -1)
         set_tuning("stream_block", 256)
         set_tuning("pipe_wgs_per_cu", 5)
 
@@ -427,3 +427,123 @@ def test_hll_from_csr_rejects_row_blocks_and_fp32(gpu):
     with sp.CsrDevice(200, 200, row_ptr, col, val.astype(np.float32)) as f32:
         with pytest.raises(RuntimeError, match="whole fp64"):
             sp.HllDevice.from_csr_device(f32)
+
+
+# --------------------------------- stream kernel with the x window in LDS
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mean,band,empty,far", [(3, 40, 0.4, 0.0), (9, 60, 0.05, 0.0), (27, 200, 0.0, 0.3),
+                                                 (64, 300, 0.0, 0.0), (300, 900, 0.0, 0.0),
+                                                 (1500, 1900, 0.0, 0.0)])
+def test_x_window_stream_kernel_matches_oracle_and_gather_kernel(gpu, oracle, dtype, mean, band, empty, far):
+    """csr_stream_local (x lines staged in LDS, 16-bit local columns) on banded matrices over
+    all block regimes: many tiny rows (row cap), ~75 rows per block, a few long rows per block,
+    blocks cut by the line limit, partial last blocks.  Checked against the oracle and, bit
+    for bit, against csr_stream (same products, same summation order), launched repeatedly
+    into a poisoned y."""
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    from _util import banded_csr
+    rng = np.random.default_rng(4000 + mean)
+    M, N = 5003, 5600
+    row_ptr, col, val = banded_csr(rng, M, N, mean, band, empty, dtype=dtype, far_frac=far)
+    x = rng.uniform(-1, 1, N).astype(dtype)
+    y_ref = oracle.csr_serial(row_ptr, col, val, x) if dtype == np.float64 else \
+        oracle.csr_f32_accum64(row_ptr, col, val, x)
+    item = np.dtype(dtype).itemsize
+    try:
+        set_tuning("stream_cap", 2048)
+        with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
+            info = dev.info()
+            assert info["local_blocks"] > 0, "banded matrix should get an x-window plan"
+            assert 32 <= info["local_stage_lines"] <= 256 and info["local_stage_lines"] % 32 == 0
+            assert info["stream_bytes"] < info["algo_bytes"]
+            dev.set_x(x)
+            set_tuning("stream_kind", 0)
+            dev.run(sp.CSR_STREAM)
+            y_gather = dev.get_y()
+            for kind in (5, -1):
+                set_tuning("stream_kind", kind)
+                for rep in range(3):
+                    sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * item)
+                    dev.run(sp.CSR_STREAM)
+                    y = dev.get_y()
+                    assert y.tobytes() == y_gather.tobytes(), f"kind={kind} rep={rep} differs from csr_stream"
+            if dtype == np.float64:
+                assert_parity(y, y_ref, row_ptr, col, val, x, what=f"x-window mean={mean}")
+            else:
+                err = np.max(np.abs(y.astype(np.float64) - y_ref)) / np.max(np.abs(y_ref))
+                assert err <= FP32_NORMWISE_RTOL
+    finally:
+        set_tuning("stream_cap", 0)
+        set_tuning("stream_kind", -1)
+
+
+def test_x_window_plan_is_refused_for_scattered_columns(gpu, oracle):
+    """Uniformly random columns: a block of 2048 entries touches far more than 256 lines, the
+    plan is not built and AUTO stays on the gather kernel; a row that alone needs more lines
+    than a block may list does the same."""
+    rng = np.random.default_rng(8)
+    row_ptr, col, val = random_csr(rng, 3000, 40000, 30, 60, 0.0)
+    x = rng.uniform(-1, 1, 40000)
+    with sp.CsrDevice(3000, 40000, row_ptr, col, val) as dev:
+        assert dev.info()["local_blocks"] == 0 and dev.info()["stream_bytes"] == 0
+        assert_parity(dev.spmv(x, sp.CSR_STREAM), oracle.csr_serial(row_ptr, col, val, x), row_ptr, col, val, x)
+    lens = np.full(50, 20)
+    lens[7] = 1000   # 1000 columns spread over 50 000: ~1000 lines in one row
+    row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(50000, n, replace=False)) if n == 1000 else
+                          np.arange(n) + 10 for n in lens]).astype(np.int32)
+    val = rng.uniform(-1, 1, row_ptr[-1])
+    x = rng.uniform(-1, 1, 50000)
+    with sp.CsrDevice(50, 50000, row_ptr, col, val) as dev:
+        assert dev.info()["local_blocks"] == 0
+        assert_parity(dev.spmv(x, sp.CSR_STREAM), oracle.csr_serial(row_ptr, col, val, x), row_ptr, col, val, x)
+
+
+def test_x_window_kernel_with_long_rows_row_blocks_and_foreign_x(gpu, oracle):
+    """Long rows go to the split-row kernels beside the x-window blocks; a row block keeps
+    global columns; run_on with a 128-byte aligned x uses the x-window kernel, a misaligned x
+    silently takes the gather kernel (whole-line reads need the alignment)."""
+    from _util import banded_csr
+    rng = np.random.default_rng(31)
+    M, N = 3000, 3000
+    row_ptr, col, val = banded_csr(rng, M, N, 40, 150)
+    lens = np.diff(row_ptr).astype(np.int64)
+    lens[1000] = 2500                     # longer than the 2048-entry stage
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols, vals = [], []
+    for r in range(M):
+        if r == 1000:
+            c = np.sort(rng.choice(N, 2500, replace=False)).astype(np.int32)
+            cols.append(c); vals.append(rng.uniform(-1, 1, 2500))
+        else:
+            cols.append(col[row_ptr[r]:row_ptr[r + 1]]); vals.append(val[row_ptr[r]:row_ptr[r + 1]])
+    col, val, row_ptr = np.concatenate(cols).astype(np.int32), np.concatenate(vals), rp
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_serial(row_ptr, col, val, x)
+    with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
+        assert dev.info()["local_blocks"] > 0 and dev.info()["long_rows"] == 1
+        assert_parity(dev.spmv(x, sp.CSR_STREAM), y_ref, row_ptr, col, val, x, what="x-window + long row")
+        # foreign x / y buffers: aligned, then shifted by one element
+        L = sp.lib()
+        import ctypes as C
+        buf = C.c_void_p()
+        assert L.spmv_hip_malloc(C.byref(buf), (N + 32) * 8) == 0
+        ybuf = C.c_void_p()
+        assert L.spmv_hip_malloc(C.byref(ybuf), M * 8) == 0
+        try:
+            for shift in (0, 8):
+                xp = C.c_void_p(buf.value + shift)
+                assert L.spmv_hip_memcpy_h2d(xp, x.ctypes.data_as(C.c_void_p), N * 8) == 0
+                assert L.spmv_hip_memset(ybuf, 0xFF, M * 8) == 0
+                assert L.spmv_hip_csr_run_on(dev.h, sp.CSR_STREAM, xp, ybuf, None) == 0
+                y = np.empty(M)
+                assert L.spmv_hip_memcpy_d2h(y.ctypes.data_as(C.c_void_p), ybuf, M * 8) == 0
+                assert_parity(y, y_ref, row_ptr, col, val, x, what=f"run_on shift={shift}")
+        finally:
+            L.spmv_hip_free(buf)
+            L.spmv_hip_free(ybuf)
+    with sp.CsrDevice(M, N, row_ptr, col, val, row0=700, row1=2100) as part:
+        assert part.info()["local_blocks"] > 0
+        y = part.spmv(x, sp.CSR_STREAM)
+        assert_parity(y[700:2100], y_ref[700:2100], row_ptr[700:2101] - row_ptr[700],
+                      col[row_ptr[700]:row_ptr[2100]], val[row_ptr[700]:row_ptr[2100]], x, what="row block")

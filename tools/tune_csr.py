@@ -29,14 +29,22 @@ for cap in (2048, 4096, 8192):
     devs[cap] = d
 info = devs[2048].info()
 algo = info["algo_bytes"]
-print(f"{which}: M={M} nnz={info['nz']} algo_bytes={algo} lanes_per_row={info['lanes_per_row']}")
+print(f"{which}: M={M} nnz={info['nz']} algo_bytes={algo} lanes_per_row={info['lanes_per_row']} "
+      f"local_blocks={info['local_blocks']} (prod {info['stream_blocks']}) stage_lines={info['local_stage_lines']} "
+      f"lines={info['local_lines']} stream_bytes={info['stream_bytes']}")
 arms = [(f"prod cap={cap} block={blk}", dict(stream_kind=0, stream_block=blk, stream_nt=1, stream_xcd=0), cap, sp.CSR_STREAM)
         for cap, blk in ((2048, 256), (4096, 256), (4096, 512))]
-arms += [(f"walk cap={cap}", dict(stream_kind=1, stream_nt=1), cap, sp.CSR_STREAM) for cap in (2048, 4096)]
-arms += [(f"RING cap=2048 wgs/cu={w} nt={nt}", dict(stream_kind=4, stream_nt=nt, pipe_wgs_per_cu=w), 2048, sp.CSR_STREAM)
-         for w in (1, 2) for nt in (1, 0)]
-arms += [(f"pipe cap={cap} wgs/cu={w} nt={nt}", dict(stream_kind=2, stream_nt=nt, pipe_wgs_per_cu=w), cap, sp.CSR_STREAM)
-         for cap in (2048, 4096) for w in (4,) for nt in (1,)]
+arms += [("x-window (local) cap=2048", dict(stream_kind=5, stream_nt=1, stream_xcd=0), 2048, sp.CSR_STREAM),
+         ("x-window (local) nt=0", dict(stream_kind=5, stream_nt=0, stream_xcd=0), 2048, sp.CSR_STREAM),
+         ("x-window (local) xcd=-1", dict(stream_kind=5, stream_nt=1, stream_xcd=-1), 2048, sp.CSR_STREAM),
+         ] + [(f"x-window (local) xcd={c}", dict(stream_kind=5, stream_nt=1, stream_xcd=c), 2048, sp.CSR_STREAM)
+              for c in (4, 8, 16, 32, 64, 128, 256, 1024)]
+if os.environ.get("TUNE_ALL"):
+    arms += [(f"walk cap={cap}", dict(stream_kind=1, stream_nt=1), cap, sp.CSR_STREAM) for cap in (2048, 4096)]
+    arms += [(f"RING cap=2048 wgs/cu={w} nt={nt}", dict(stream_kind=4, stream_nt=nt, pipe_wgs_per_cu=w), 2048, sp.CSR_STREAM)
+             for w in (1, 2) for nt in (1, 0)]
+    arms += [(f"pipe cap={cap} wgs/cu={w} nt={nt}", dict(stream_kind=2, stream_nt=nt, pipe_wgs_per_cu=w), cap, sp.CSR_STREAM)
+             for cap in (2048, 4096) for w in (4,) for nt in (1,)]
 arms += [(f"PROBE cap=4096 " + name, dict(stream_kind=10 + mode), 4096, sp.CSR_STREAM)
          for mode, name in ((0, "stream only"), (3, "all (= prod)"))]
 arms += [("subwave", {}, 2048, sp.CSR_SUBWAVE), ("wave_row", {}, 2048, sp.CSR_WAVE_ROW)]
