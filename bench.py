@@ -222,6 +222,8 @@ def side_measurement(sp, synth, which, steps, warmup):
                 "auto": {"gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
                          "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
                          "pct_of_8TBs": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9 / 80.0, 2),
+                         "kernel": "csr_stream_local" if info["local_blocks"] else "csr_stream",
+                         "format_bytes": info["stream_bytes"] or info["algo_bytes"],
                          "us": round(float(ms.mean()) * 1e3, 2)}}
     M, row_ptr, col, val = synth.fem_like()
     nnz = int(row_ptr[-1])
@@ -236,6 +238,7 @@ def side_measurement(sp, synth, which, steps, warmup):
                 out[name] = {"gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
                              "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
                              "us": round(float(ms.mean()) * 1e3, 2)}
+        out["stream"]["kernel"] = "csr_stream_local" if info["local_blocks"] else "csr_stream"
         return {"workload": "cant-like fp64 CSR (M=62451, nnz=%d; Infinity-Cache resident)" % nnz,
                 "algo_bytes": info["algo_bytes"], **out}
     from _bench_util import coo_of
@@ -401,7 +404,8 @@ def main():
         ms_xchg = np.array([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)])
 
     stats = torch.tensor([wall, float(np.mean(ms_kernel)), float(np.mean(ms_xchg)) if ms_xchg is not None else 0.0,
-                          float(info["algo_bytes"]), float(info["nz"])], dtype=torch.float64)
+                          float(info["algo_bytes"]), float(info["nz"]),
+                          float(info.get("stream_bytes", 0))], dtype=torch.float64)
     if world > 1:
         if exchange != "gloo-host":
             stats = stats.cuda()
@@ -436,9 +440,13 @@ def main():
         slow = int(np.argmax(per_rank[:, 1]))
         k_ms = float(per_rank[slow, 1])
         achieved = per_rank[slow, 3] / (k_ms * 1e-3) / 1e9
+        # the STREAM variant runs csr_stream_local (x lines staged in LDS, 16-bit local columns)
+        # when upload found a plan for the matrix, else csr_stream (gathers)
+        stream_name = "csr_stream_local" if (not hll_mode and info.get("local_blocks", 0) > 0) else "csr_stream"
         kernel_name = ("hll_lds" if hll_mode else
-                       {0: "csr_stream", 1: "csr_thread_row", 2: "csr_vector<64,2>", 3: "csr_vector<L,1>",
-                        4: "csr_stream"}[variant if variant else info["auto_variant"]])
+                       {0: stream_name, 1: "csr_thread_row", 2: "csr_vector<64,2>", 3: "csr_vector<L,1>",
+                        4: stream_name}[variant if variant else info["auto_variant"]])
+        moved = float(per_rank[slow, 5]) if kernel_name == "csr_stream_local" else float(per_rank[slow, 3])
         result = {
             "metric": "SpMV GFLOP/s (2*nnz flops / step time); achieved HBM GB/s and % of 8 TB/s alongside",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -459,6 +467,12 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": measured_traffic(kernel_name, wl["name"]),
                          "algorithmic_bytes_per_launch": int(per_rank[slow, 3]),
+                         # what the kernel's own format streams from HBM (2-byte local columns + line
+                         # lists instead of 4-byte columns for csr_stream_local); `achieved` above is
+                         # by the CSR formula of SURVEY 8(d), this is the same time priced by these bytes
+                         "format_bytes_per_launch": int(moved),
+                         "achieved_by_format_bytes": round(moved / (k_ms * 1e-3) / 1e9, 1),
+                         "frac_by_format_bytes": round(moved / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "kernel_ms_mean": round(k_ms, 5),
                          "kernel_ms_min": round(float(np.min(ms_kernel)), 5) if slow == 0 else None},
         }

@@ -460,9 +460,22 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     m->max_row = max_row;
 
     std::vector<int4> desc, pieces, long_rows;
-    // larger stages amortise per-workgroup latency on big matrices; small ones need
+    // The x-window kernel first (csr_stream_local): own blocks at a 2048-entry stage.  One stage
+    // size per handle, so that its blocks, the gather kernel's and the split long rows agree on
+    // which rows are long: a matrix that gets a plan runs everything at 2048.  An explicit
+    // stream_cap other than 2048 asks for the gather kernel's configuration and skips the plan.
+    LocalPlan local;
+    bool have_local = false;
+    constexpr int line_shift = sizeof(T) == 8 ? 4 : 5;  // 128-byte lines
+    if (g_stream_local && nz > 0 && (g_stream_cap == 0 || g_stream_cap == 2048)) {
+        csr_build_blocks(Ml, rp.data(), 2048, kStreamRowsCap, desc, pieces, long_rows);
+        have_local = csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, 2048, kStreamRowsCap, line_shift,
+                                     kLocalLinesMax, desc, local);
+    }
+    // else: larger stages amortise per-workgroup latency on big matrices; small ones need
     // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
-    m->stream_cap = g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048);
+    m->stream_cap = have_local ? 2048 : (g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048));
+    m->local_cap = 2048;
     // the ring kernel stages at most kRingRows - 1 rows per block; only worth it when such
     // blocks are still (nearly) full, i.e. rows are not tiny
     m->ring_ok = m->stream_cap == kRingCap && Ml > 0 && (double)nz / Ml >= 1.25 * kRingCap / (kRingRows - 1);
@@ -472,19 +485,6 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     m->num_long = (int)long_rows.size();
     m->num_partial = (int)pieces.size();
     const int num_partial = m->num_partial;
-
-    // the x-window kernel: own blocks (cap 2048: LDS holds products AND the staged lines)
-    LocalPlan local;
-    bool have_local = false;
-    if (g_stream_local && nz > 0) {
-        std::vector<int4> base_desc, p2, l2;
-        m->local_cap = 2048;
-        if (m->stream_cap == m->local_cap && !m->ring_ok) base_desc = desc;
-        else csr_build_blocks(Ml, rp.data(), m->local_cap, kStreamRowsCap, base_desc, p2, l2);
-        constexpr int line_shift = sizeof(T) == 8 ? 4 : 5;  // 128-byte lines
-        have_local = csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, m->local_cap, kStreamRowsCap, line_shift,
-                                     kLocalLinesMax, base_desc, local);
-    }
 
     int rc = 0;
     rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), (size_t)kRingRows + 64);
