@@ -151,6 +151,8 @@ int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_de
 int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out);
 /* flat slab back to the host: hack_off[hacks + 1] (slot offsets, each hack starts on an even
  * slot), maxnz[hacks], JA / AS [hack_off[hacks]]; any pointer may be NULL */
+void *spmv_hip_hll_x_ptr(spmv_hll_dev *m); /* device pointers of the handle's x [N] and y [M] */
+void *spmv_hip_hll_y_ptr(spmv_hll_dev *m);
 int spmv_hip_hll_download(const spmv_hll_dev *m, long long *hack_off, int *maxnz, int *JA, double *AS);
 void spmv_hip_hll_free(spmv_hll_dev *m);
 int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out);

@@ -222,6 +222,101 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
     }
 }
 
+// hll_lds with the x window in LDS: same windows idea, but the window's x lines are staged in
+// LDS by full-width loads and JA is replaced by 16-bit slots into that stage -- the HLL twin of
+// csr_stream_local (see csr_kernels.hpp for the reasoning and the line-list format).  Windows
+// are cut at upload with both limits (kLocalCap slots, kLocalLinesMax lines); padding slots
+// repeat the row's last column, so they add no lines.
+template <typename T, bool NT, int CAP>
+__global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_chunk,
+                                                        const int4 *__restrict__ desc,
+                                                        const int2 *__restrict__ ldesc,
+                                                        const int *__restrict__ lines,
+                                                        const long long *__restrict__ hack_off,
+                                                        const int *__restrict__ maxnz,
+                                                        const unsigned short *__restrict__ lja,
+                                                        const T *__restrict__ AS,
+                                                        const T *__restrict__ x, T *__restrict__ y) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
+    extern __shared__ __align__(16) unsigned char hll_local_lds[];
+    T *stage = reinterpret_cast<T *>(hll_local_lds);  // x lines first, then the products
+
+    const int b = xcd_chunked(blockIdx.x, xcd_chunk);
+    if (b >= num_blocks) return;
+    const int t = threadIdx.x;
+    const int4 d = desc[b];
+    const int2 ld = ldesc[b];
+    const int row_first = d.x, nrows = d.y;
+    const long long first_slot = ((long long)d.w << 32) | (unsigned)d.z;
+    const long long base = first_slot & ~1LL;
+
+    auto row_range = [&](int q, int &lo, int &m) {
+        const int r = row_first + q;
+        const int h = r / kHack;
+        m = maxnz[h];
+        lo = (int)(hack_off[h] + (long long)(r % kHack) * m - base);
+    };
+    const int lanes = lanes_for_rows<kBlock>(nrows);
+    const int rows_per_pass = kBlock / lanes;
+    const int my_row = t / lanes, my_lane = t % lanes;
+    int lo = 0, m_row = 0;
+    if (my_row < nrows) row_range(my_row, lo, m_row);
+    int last_lo, last_m;
+    row_range(nrows - 1, last_lo, last_m);
+    const int count = last_lo + last_m;                                       // slots from base
+    const int units = (count + kUnit - 1) / kUnit;                            // wave-uniform
+    const int rounds = (ld.y + kLocalLineQuantum - 1) / kLocalLineQuantum;    // wave-uniform
+    const int *my_lines = lines + ld.x;
+    const unsigned short *wj = lja + base;
+    const T *wa = AS + base;
+    if (units == kUnits) {
+        switch (rounds) {
+            case 1: local_stage_full<T, NT, CAP, 1>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+            case 2: local_stage_full<T, NT, CAP, 2>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+            case 3: local_stage_full<T, NT, CAP, 3>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+            case 4: local_stage_full<T, NT, CAP, 4>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+            case 5: local_stage_full<T, NT, CAP, 5>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+            case 6: local_stage_full<T, NT, CAP, 6>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+            case 7: local_stage_full<T, NT, CAP, 7>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+            default: local_stage_full<T, NT, CAP, 8>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
+        }
+    } else {
+        for (int k = 0; k < rounds; ++k) {
+            const int line = my_lines[min(k * kLocalLineQuantum + (t >> 3), ld.y - 1)];
+            const unsigned off = (unsigned)line * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) =
+                *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+        }
+        __syncthreads();
+        V2 p[kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            if (u < units) {
+                const unsigned c = stream_load<NT>(reinterpret_cast<const unsigned *>(wj + 2 * t + u * kUnit));
+                p[u] = stream_load<NT>(reinterpret_cast<const V2 *>(wa + 2 * t + u * kUnit));
+                p[u].x *= stage[c & 0xffffu];
+                p[u].y *= stage[c >> 16];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u)
+            if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = p[u];
+    }
+    __syncthreads();
+    for (int first = 0; first < nrows; first += rows_per_pass) {
+        const int q = first + my_row;
+        if (first > 0) {
+            lo = m_row = 0;
+            if (q < nrows) row_range(q, lo, m_row);
+        }
+        T acc = lds_strided_sum(stage, lo, lo + m_row, my_lane, lanes);
+        acc = group_sum_rt(acc, lanes);
+        if (my_lane == 0 && q < nrows) y[row_first + q] = acc;
+    }
+}
+
 // ------------------------------------------------------ CSR -> HLL on the device
 // the reference builds HLL on the host with one qsort and two mallocs
 // per row / hack (src/hll_matrix.c:37-257) and uploads hack by hack.  With the CSR matrix

@@ -141,6 +141,13 @@ struct spmv_hll_dev {
     int4 *hdesc = nullptr;  // [num_blocks] {first row, rows, first slot lo, first slot hi}
     int num_blocks = 0;
     int stage_slots = kHllCap;  // LDS stage of hll_lds: the largest workgroup, <= kHllCap
+    // hll_lds_local (x window in LDS): own windows, 16-bit local JA
+    int4 *ldesc4 = nullptr;
+    int2 *ldesc = nullptr;
+    int *lines = nullptr;
+    unsigned short *lja = nullptr;
+    int local_blocks = 0, local_stage_lines = 0;
+    long long local_lines = 0;
     double *x = nullptr;
     double *y = nullptr;
     int lanes_per_row = 8;
@@ -393,6 +400,7 @@ bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, 
             ++r1;
         }
         if (r1 == r) return false;  // one row alone touches more lines than a block may list
+        if (cur.empty()) cur.push_back(0);  // only empty rows: the kernel still stages one line
         std::sort(cur.begin(), cur.end());
         for (size_t k = 0; k < cur.size(); ++k) rank[cur[k]] = (int)k;
         for (int e = rp[r]; e < rp[r1]; ++e)
@@ -856,6 +864,68 @@ long long hll_build_blocks(int M, int hacks, const long long *off, const int *mz
 
 namespace {
 
+// Windows for hll_lds_local: hll_build_blocks' cut at `cap` slots with the line limit on top
+// (see csr_build_local).  ja is the flat host slab.  false: keep the gather kernel.
+bool hll_build_local(int M, int N, const long long *off, const int *mz, const int *ja, long long slots_padded,
+                     int cap, int lines_max, const std::vector<int4> &baseline, LocalPlan &plan) {
+    constexpr int line_shift = 4;  // fp64: 16 per 128-byte line
+    const int total_lines = (int)(((long long)N + 15) >> line_shift);
+    std::vector<int> stamp((size_t)total_lines + 1, -1), rank((size_t)total_lines + 1, 0), cur;
+    plan.lcol.assign((size_t)slots_padded + kPad, 0);
+    plan.desc.clear();
+    plan.ldesc.clear();
+    plan.lines.clear();
+    int widest = 0;
+    auto start_of = [&](int r) { return off[r / kHack] + (long long)(r % kHack) * mz[r / kHack]; };
+    int r = 0;
+    while (r < M) {
+        const long long s0 = start_of(r);
+        const long long base = s0 & ~1LL;
+        const int blk = (int)plan.desc.size();
+        cur.clear();
+        int r1 = r;
+        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap) {
+            const size_t before = cur.size();
+            const long long a = start_of(r1);
+            for (long long k = a; k < a + mz[r1 / kHack]; ++k) {
+                const int l = ja[k] >> line_shift;
+                if (stamp[l] != blk) {
+                    stamp[l] = blk;
+                    cur.push_back(l);
+                }
+            }
+            if ((int)cur.size() > lines_max) {
+                for (size_t k = before; k < cur.size(); ++k) stamp[cur[k]] = -1;
+                cur.resize(before);
+                break;
+            }
+            ++r1;
+        }
+        if (r1 == r) return false;  // a row that alone exceeds the stage or the line limit
+        if (cur.empty()) cur.push_back(0);  // rows without slots: the kernel still stages one line
+        std::sort(cur.begin(), cur.end());
+        for (size_t k = 0; k < cur.size(); ++k) rank[cur[k]] = (int)k;
+        for (long long k = s0; k < start_of(r1 - 1) + mz[(r1 - 1) / kHack]; ++k)
+            plan.lcol[k] = (unsigned short)((rank[ja[k] >> line_shift] << line_shift) | (ja[k] & 15));
+        plan.desc.push_back(int4{r, r1 - r, (int)(s0 & 0xffffffffLL), (int)(s0 >> 32)});
+        plan.ldesc.push_back(int2{(int)plan.lines.size(), (int)cur.size()});
+        plan.lines.insert(plan.lines.end(), cur.begin(), cur.end());
+        widest = std::max(widest, (int)cur.size());
+        r = r1;
+        if ((plan.desc.size() & 1023) == 0) {
+            const size_t plain = std::lower_bound(baseline.begin(), baseline.end(), r,
+                                                  [](const int4 &d, int row) { return d.x < row; }) -
+                                 baseline.begin();
+            if (plan.desc.size() > plain + plain / 5 + 16) return false;
+        }
+    }
+    if (plan.desc.size() > baseline.size() + baseline.size() / 5 + 1) return false;
+    plan.stage_lines = std::max(kLocalLineQuantum,
+                                (widest + kLocalLineQuantum - 1) / kLocalLineQuantum * kLocalLineQuantum);
+    plan.lines.insert(plan.lines.end(), (size_t)kLocalLinesMax, 0);
+    return true;
+}
+
 // offsets of the hacks in the flat slab: every hack starts on an even slot
 long long hll_offsets(int total_rows, const std::vector<int> &mz, std::vector<long long> &off,
                       long long &true_slots) {
@@ -873,7 +943,7 @@ long long hll_offsets(int total_rows, const std::vector<int> &mz, std::vector<lo
 
 // workgroup windows, small arrays and vectors of a handle whose JA / AS are already on the device
 int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<long long> &off,
-                      const std::vector<int> &mz, long long true_slots, bool upload_maxnz) {
+                      const std::vector<int> &mz, long long true_slots, bool upload_maxnz, const int *ja_host) {
     const int H = (int)mz.size();
     // like the CSR stream kernel: larger stages for matrices that have plenty of work
     const int cap = true_slots >= (16LL << 20) ? kHllCap : kHllCap / 2;
@@ -887,18 +957,37 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
     m->num_blocks = (int)hdesc.size();
     m->stage_slots = (int)std::min<long long>(kHllCap, (widest + kStreamUnit - 1) / kStreamUnit * kStreamUnit);
     int rc = 0;
-    rc |= upload_array(&m->hack_off, off.data(), off.size(), 0);
+    if (!m->hack_off) rc |= upload_array(&m->hack_off, off.data(), off.size(), 0);
     if (!rc && upload_maxnz) rc |= upload_array(&m->maxnz, mz.data(), mz.size(), 1);
     if (!rc) rc |= upload_array(&m->hdesc, hdesc.data(), hdesc.size(), 1);
     if (!rc) {
-        hipError_t e = hipMalloc((void **)&m->x, std::max<size_t>((size_t)N, 1) * sizeof(double));
+        const size_t x_bytes = std::max<size_t>((size_t)N, 1) * sizeof(double) + kLineBytes;  // whole-line reads
+        hipError_t e = hipMalloc((void **)&m->x, x_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(m->x, 0, std::max<size_t>((size_t)N, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(m->x, 0, x_bytes);
         if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
         if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
     }
     m->device_bytes = off.size() * 8 + mz.size() * 4 + ((size_t)off[H] + kPad) * 12 + hdesc.size() * 16 +
                       ((size_t)N + (size_t)total_rows) * 8;
+    // the x-window kernel: windows of 2048 slots, 16-bit local JA (needs the slab on the host)
+    if (!rc && ja_host && g_stream_local && true_slots > 0) {
+        std::vector<int4> plain;
+        LocalPlan local;
+        hll_build_blocks(total_rows, H, off.data(), mz.data(), 2048, plain);
+        if (hll_build_local(total_rows, N, off.data(), mz.data(), ja_host, off[H], 2048, kLocalLinesMax, plain, local)) {
+            rc |= upload_array(&m->ldesc4, local.desc.data(), local.desc.size(), 1);
+            if (!rc) rc |= upload_array(&m->ldesc, local.ldesc.data(), local.ldesc.size(), 1);
+            if (!rc) rc |= upload_array(&m->lines, local.lines.data(), local.lines.size(), 0);
+            if (!rc) rc |= upload_array(&m->lja, local.lcol.data(), local.lcol.size(), 0);
+            if (!rc) {
+                m->local_blocks = (int)local.desc.size();
+                m->local_stage_lines = local.stage_lines;
+                m->local_lines = (long long)local.lines.size() - kLocalLinesMax;
+                m->device_bytes += local.desc.size() * 24 + local.lines.size() * 4 + local.lcol.size() * 2;
+            }
+        }
+    }
     const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
     m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
     return rc;
@@ -948,7 +1037,7 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
     if (!m) return fail("hll_upload: out of host memory");
     int rc = upload_array(&m->JA, ja.data(), ja.size(), 0);
     if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
-    if (!rc) rc |= hll_finish_handle(m, total_rows, N, off, mz, true_slots, true);
+    if (!rc) rc |= hll_finish_handle(m, total_rows, N, off, mz, true_slots, true, ja.data());
     if (rc) {
         spmv_hip_hll_free(m);
         return -1;
@@ -988,7 +1077,7 @@ extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out
         if (e == hipSuccess) e = hipMemsetAsync(m->JA, 0, ((size_t)S + kPad) * sizeof(int), g_stream);
         if (e == hipSuccess) e = hipMemsetAsync(m->AS, 0, ((size_t)S + kPad) * sizeof(double), g_stream);
         if (e != hipSuccess) { rc = fail("hll_from_csr: slab allocation failed: %s", hipGetErrorString(e)); break; }
-        rc = hll_finish_handle(m, M, N, off, mz, true_slots, false);
+        rc = upload_array(&m->hack_off, off.data(), off.size(), 0);
         if (rc) break;
         if (M > 0) {
             hipLaunchKernelGGL((hll_fill_from_csr<double>), dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
@@ -998,6 +1087,14 @@ extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out
             if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
             if (e != hipSuccess) { rc = fail("hll_from_csr: fill failed: %s", hipGetErrorString(e)); break; }
         }
+        // the x-window plan is built on the host from the finished JA (one D2H copy of 4 bytes per slot)
+        std::vector<int> ja_host;
+        if (g_stream_local && S > 0) {
+            ja_host.resize((size_t)S);
+            e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
+        }
+        rc = hll_finish_handle(m, M, N, off, mz, true_slots, false, ja_host.empty() ? nullptr : ja_host.data());
     } while (0);
     if (rc) {
         spmv_hip_hll_free(m);
@@ -1030,6 +1127,10 @@ extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
     (void)hipFree(m->JA);
     (void)hipFree(m->AS);
     (void)hipFree(m->hdesc);
+    (void)hipFree(m->ldesc4);
+    (void)hipFree(m->ldesc);
+    (void)hipFree(m->lines);
+    (void)hipFree(m->lja);
     (void)hipFree(m->x);
     (void)hipFree(m->y);
     delete m;
@@ -1049,8 +1150,17 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     // S (val + 4) + 12 H + val (M + N)
     out->algo_bytes = m->slots * 12 + 12LL * m->hacks + 8LL * ((long long)m->M + m->N);
     out->device_bytes = (long long)m->device_bytes;
+    out->local_blocks = m->local_blocks;
+    out->local_stage_lines = m->local_stage_lines;
+    out->local_lines = m->local_lines;
+    if (m->local_blocks > 0)
+        out->stream_bytes = m->slots * 10 + 4 * m->local_lines + 24LL * m->local_blocks + 12LL * m->hacks +
+                            8LL * ((long long)m->M + m->N);
     return 0;
 }
+
+extern "C" void *spmv_hip_hll_x_ptr(spmv_hll_dev *m) { return m ? m->x : nullptr; }
+extern "C" void *spmv_hip_hll_y_ptr(spmv_hll_dev *m) { return m ? m->y : nullptr; }
 
 extern "C" int spmv_hip_hll_set_x(spmv_hll_dev *m, const double *x_host) {
     if (need_device()) return -1;
@@ -1095,6 +1205,16 @@ int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y, h
             }
             break;
         case SPMV_HLL_LDS: {
+            if ((g_stream_kind == -1 || g_stream_kind == 5) && m->local_blocks > 0 &&
+                ((uintptr_t)x & (kLineBytes - 1)) == 0) {
+                const int lchunk = g_stream_xcd < 0 ? (m->local_blocks + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
+                const int lgrid = (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk);
+                const size_t llds = std::max((size_t)2048 * sizeof(double), (size_t)m->local_stage_lines * kLineBytes);
+                hipLaunchKernelGGL((hll_lds_local<double, true, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
+                                   m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
+                                   m->lja, m->AS, x, y);
+                break;
+            }
             const size_t lds = 32 + ((size_t)m->stage_slots + 2) * sizeof(double);
 #define SPMV_HLL_LDS_LAUNCH(MAXU)                                                                  \
     hipLaunchKernelGGL((hll_lds<double, true, MAXU>), dim3(m->num_blocks), dim3(kBlock), lds, s,    \

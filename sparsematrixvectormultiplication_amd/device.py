@@ -184,6 +184,9 @@ class HllDevice(_Handle):
         self.M, self.N = csr.M, csr.N
         return self
 
+    x_ptr = property(lambda s: nat.lib().spmv_hip_hll_x_ptr(s.h) or 0)
+    y_ptr = property(lambda s: nat.lib().spmv_hip_hll_y_ptr(s.h) or 0)
+
     def download(self):
         """(hack_off, maxnz, JA, AS) of the flat device slab."""
         info = self.info()

@@ -547,3 +547,43 @@ def test_x_window_kernel_with_long_rows_row_blocks_and_foreign_x(gpu, oracle):
         y = part.spmv(x, sp.CSR_STREAM)
         assert_parity(y[700:2100], y_ref[700:2100], row_ptr[700:2101] - row_ptr[700],
                       col[row_ptr[700]:row_ptr[2100]], val[row_ptr[700]:row_ptr[2100]], x, what="row block")
+
+
+@pytest.mark.parametrize("mean,band,empty,far", [(3, 40, 0.4, 0.0), (27, 200, 0.0, 0.3), (64, 300, 0.02, 0.0),
+                                                 (300, 900, 0.0, 0.0)])
+def test_hll_x_window_kernel_matches_oracle(gpu, oracle, mean, band, empty, far):
+    """hll_lds_local (x lines staged in LDS, 16-bit local JA) on banded matrices: windows cut
+    by slots, by the line limit and by the row cap; padding slots; M not a multiple of 32."""
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    from _util import banded_csr
+    rng = np.random.default_rng(6000 + mean)
+    M, N = 4099, 4500
+    row_ptr, col, val = banded_csr(rng, M, N, mean, band, empty, far_frac=far)
+    r, c, v = coo_from_csr(row_ptr, col, val, rng)
+    hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, N, r, c, v))
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_serial(row_ptr, col, val, x)
+    try:
+        with sp.HllDevice(hll) as dev:
+            info = dev.info()
+            assert info["local_blocks"] > 0 and 0 < info["stream_bytes"] < info["algo_bytes"]
+            dev.set_x(x)
+            set_tuning("stream_kind", 0)
+            dev.run(sp.HLL_LDS)
+            y_gather = dev.get_y()
+            assert_parity(y_gather, y_ref, row_ptr, col, val, x, what="hll_lds")
+            set_tuning("stream_kind", -1)
+            first = None
+            for rep in range(3):
+                sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * 8)
+                dev.run(sp.HLL_LDS)
+                y = dev.get_y()
+                assert_parity(y, y_ref, row_ptr, col, val, x, what=f"hll_lds_local mean={mean} rep={rep}")
+                first = y if first is None else first
+                assert y.tobytes() == first.tobytes()
+        # the slab built on the device gets the same plan and the same bits
+        with sp.CsrDevice(M, N, row_ptr, col, val) as cdev, sp.HllDevice.from_csr_device(cdev) as built:
+            assert built.info()["local_blocks"] == info["local_blocks"]
+            assert built.spmv(x, sp.HLL_LDS).tobytes() == first.tobytes()
+    finally:
+        set_tuning("stream_kind", -1)
