@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
 template <typename T, bool NT, int CAP>
 __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_chunk,
                                                         const int4 *__restrict__ desc,
-                                                        const int2 *__restrict__ ldesc,
+                                                        const int4 *__restrict__ ldesc,
                                                         const int *__restrict__ lines,
                                                         const long long *__restrict__ hack_off,
                                                         const int *__restrict__ maxnz,
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
     if (b >= num_blocks) return;
     const int t = threadIdx.x;
     const int4 d = desc[b];
-    const int2 ld = ldesc[b];
+    const int4 ld = ldesc[b];  // {first line, lines, slots of the window counted from its even base, -}
     const int row_first = d.x, nrows = d.y;
     const long long first_slot = ((long long)d.w << 32) | (unsigned)d.z;
     const long long base = first_slot & ~1LL;
@@ -261,10 +261,9 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
     const int rows_per_pass = kBlock / lanes;
     const int my_row = t / lanes, my_lane = t % lanes;
     int lo = 0, m_row = 0;
-    if (my_row < nrows) row_range(my_row, lo, m_row);
-    int last_lo, last_m;
-    row_range(nrows - 1, last_lo, last_m);
-    const int count = last_lo + last_m;                                       // slots from base
+    if (my_row < nrows) row_range(my_row, lo, m_row);  // consumed after the stage: rides along with it
+    // the slot count comes with the descriptor, so the stream does not wait for the hack table
+    const int count = ld.z;
     const int units = (count + kUnit - 1) / kUnit;                            // wave-uniform
     const int rounds = (ld.y + kLocalLineQuantum - 1) / kLocalLineQuantum;    // wave-uniform
     const int *my_lines = lines + ld.x;

@@ -143,7 +143,7 @@ struct spmv_hll_dev {
     int stage_slots = kHllCap;  // LDS stage of hll_lds: the largest workgroup, <= kHllCap
     // hll_lds_local (x window in LDS): own windows, 16-bit local JA
     int4 *ldesc4 = nullptr;
-    int2 *ldesc = nullptr;
+    int4 *ldesc = nullptr;  // {first line, lines, slots of the window from its even base, 0}
     int *lines = nullptr;
     unsigned short *lja = nullptr;
     int local_blocks = 0, local_stage_lines = 0;
@@ -356,6 +356,7 @@ void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<i
 // cuts that the blocks would run mostly empty: the caller then keeps the gather kernel.
 struct LocalPlan {
     std::vector<int4> desc;
+    std::vector<int4> hll_ldesc;  // HLL: {first line, lines, slots from the even base, 0}
     std::vector<int2> ldesc;
     std::vector<int> lines;
     std::vector<unsigned short> lcol;
@@ -873,7 +874,7 @@ bool hll_build_local(int M, int N, const long long *off, const int *mz, const in
     std::vector<int> stamp((size_t)total_lines + 1, -1), rank((size_t)total_lines + 1, 0), cur;
     plan.lcol.assign((size_t)slots_padded + kPad, 0);
     plan.desc.clear();
-    plan.ldesc.clear();
+    plan.hll_ldesc.clear();
     plan.lines.clear();
     int widest = 0;
     auto start_of = [&](int r) { return off[r / kHack] + (long long)(r % kHack) * mz[r / kHack]; };
@@ -908,7 +909,8 @@ bool hll_build_local(int M, int N, const long long *off, const int *mz, const in
         for (long long k = s0; k < start_of(r1 - 1) + mz[(r1 - 1) / kHack]; ++k)
             plan.lcol[k] = (unsigned short)((rank[ja[k] >> line_shift] << line_shift) | (ja[k] & 15));
         plan.desc.push_back(int4{r, r1 - r, (int)(s0 & 0xffffffffLL), (int)(s0 >> 32)});
-        plan.ldesc.push_back(int2{(int)plan.lines.size(), (int)cur.size()});
+        plan.hll_ldesc.push_back(int4{(int)plan.lines.size(), (int)cur.size(),
+                                      (int)(start_of(r1 - 1) + mz[(r1 - 1) / kHack] - base), 0});
         plan.lines.insert(plan.lines.end(), cur.begin(), cur.end());
         widest = std::max(widest, (int)cur.size());
         r = r1;
@@ -977,14 +979,14 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
         hll_build_blocks(total_rows, H, off.data(), mz.data(), 2048, plain);
         if (hll_build_local(total_rows, N, off.data(), mz.data(), ja_host, off[H], 2048, kLocalLinesMax, plain, local)) {
             rc |= upload_array(&m->ldesc4, local.desc.data(), local.desc.size(), 1);
-            if (!rc) rc |= upload_array(&m->ldesc, local.ldesc.data(), local.ldesc.size(), 1);
+            if (!rc) rc |= upload_array(&m->ldesc, local.hll_ldesc.data(), local.hll_ldesc.size(), 1);
             if (!rc) rc |= upload_array(&m->lines, local.lines.data(), local.lines.size(), 0);
             if (!rc) rc |= upload_array(&m->lja, local.lcol.data(), local.lcol.size(), 0);
             if (!rc) {
                 m->local_blocks = (int)local.desc.size();
                 m->local_stage_lines = local.stage_lines;
                 m->local_lines = (long long)local.lines.size() - kLocalLinesMax;
-                m->device_bytes += local.desc.size() * 24 + local.lines.size() * 4 + local.lcol.size() * 2;
+                m->device_bytes += local.desc.size() * 32 + local.lines.size() * 4 + local.lcol.size() * 2;
             }
         }
     }
@@ -1154,7 +1156,7 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     out->local_stage_lines = m->local_stage_lines;
     out->local_lines = m->local_lines;
     if (m->local_blocks > 0)
-        out->stream_bytes = m->slots * 10 + 4 * m->local_lines + 24LL * m->local_blocks + 12LL * m->hacks +
+        out->stream_bytes = m->slots * 10 + 4 * m->local_lines + 32LL * m->local_blocks + 12LL * m->hacks +
                             8LL * ((long long)m->M + m->N);
     return 0;
 }
