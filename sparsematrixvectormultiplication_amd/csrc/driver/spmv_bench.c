@@ -169,13 +169,19 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
         if (ftell(fp) == 0)
             fputs("matrix_name,rows,cols,nonzeros,hll_slots,csr_algo_bytes,hll_algo_bytes,"
                   "time_stream_csr,gflops_stream_csr,gbps_stream_csr,pct_8TBs_stream_csr,"
-                  "rel_err_stream_csr,time_lds_hll,gflops_lds_hll,gbps_lds_hll,pct_8TBs_lds_hll\n", fp);
+                  "rel_err_stream_csr,time_lds_hll,gflops_lds_hll,gbps_lds_hll,pct_8TBs_lds_hll,"
+                  "kernel_stream_csr,csr_format_bytes,kernel_lds_hll,hll_format_bytes\n", fp);
         const double gb_c = (double)ci.algo_bytes / r_stream.time / 1e9;
         const double gb_h = (double)hi.algo_bytes / h_lds.time / 1e9;
-        fprintf(fp, "%s,%d,%d,%d,%lld,%lld,%lld,%.9f,%.3f,%.1f,%.2f,%.3e,%.9f,%.3f,%.1f,%.2f\n", name,
+        /* which kernel the fast path resolved to, and the bytes its own arrays amount to */
+        fprintf(fp, "%s,%d,%d,%d,%lld,%lld,%lld,%.9f,%.3f,%.1f,%.2f,%.3e,%.9f,%.3f,%.1f,%.2f,%s,%lld,%s,%lld\n", name,
                 M, N, nz, hi.slots, ci.algo_bytes, hi.algo_bytes, r_stream.time,
                 r_stream.flops / 1e9, gb_c, gb_c / 80.0, r_stream.err.mean_rel_err, h_lds.time,
-                h_lds.flops / 1e9, gb_h, gb_h / 80.0);
+                h_lds.flops / 1e9, gb_h, gb_h / 80.0,
+                ci.local_blocks > 0 ? "csr_stream_local" : "csr_stream",
+                ci.local_blocks > 0 ? ci.stream_bytes : ci.algo_bytes,
+                hi.local_blocks > 0 ? "hll_lds_local" : "hll_lds",
+                hi.local_blocks > 0 ? hi.stream_bytes : hi.algo_bytes);
         fclose(fp);
     }
     printf("%-28s M=%d nnz=%d  csr: row %.1f wave %.1f sub %.1f stream %.1f us | hll: row %.1f sub %.1f lds %.1f us"

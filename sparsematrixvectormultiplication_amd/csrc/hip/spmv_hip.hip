@@ -37,8 +37,10 @@ int g_comm_rank = 0, g_comm_size = 1;
 // kernel tuning knobs (spmv_hip_set_tuning); defaults are the measured best
 int g_stream_cap = 0;     // nnz staged per stream workgroup (fixed at upload); 0 = by matrix size
 int g_stream_block = 256; // threads per csr_stream workgroup
-int g_stream_nt = 1;      // non-temporal loads for col/val
+int g_stream_nt = 1;      // non-temporal loads for col/val in the gather stream kernels
+int g_local_nt = -1;      // same for the x-window kernel: -1 = auto (off while the matrix fits the Infinity Cache)
 int g_stream_xcd = 0;     // blocks per XCD run (xcd_chunked); 0 = dispatch order, -1 = one contiguous eighth per XCD
+int g_local_cap = 0;       // stage of the x-window plan: 0 = auto, 1024 or 2048
 int g_stream_local = 1;    // build the x-window plan at upload (csr_stream_local) when it pays
 int g_stream_kind = -1;    // -1 = auto (csr_stream_local when the matrix has a plan, else csr_stream), 5 = local,
                            // 0 = csr_stream (products), 1 = csr_stream_rows (row walk), 2 = csr_stream_pipe
@@ -220,8 +222,8 @@ extern "C" int spmv_hip_shutdown(void) {
 extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     if (!key) return fail("set_tuning: NULL key");
     if (!strcmp(key, "stream_cap")) {
-        if (value != 0 && value != 2048 && value != 4096 && value != 8192)
-            return fail("set_tuning: stream_cap must be 0 (auto), 2048, 4096 or 8192");
+        if (value != 0 && value != 1024 && value != 2048 && value != 4096 && value != 8192)
+            return fail("set_tuning: stream_cap must be 0 (auto), 1024, 2048, 4096 or 8192");
         g_stream_cap = value;
     } else if (!strcmp(key, "stream_block")) {
         if (value != 256 && value != 512 && value != 1024)
@@ -238,6 +240,12 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         if ((value < -1 || value > 5) && (value < 10 || value > 17))
             return fail("set_tuning: stream_kind must be -1..5 (or 10..17 for the ablation probes)");
         g_stream_kind = value;
+    } else if (!strcmp(key, "local_nt")) {
+        if (value < -1 || value > 1) return fail("set_tuning: local_nt must be -1 (auto), 0 or 1");
+        g_local_nt = value;
+    } else if (!strcmp(key, "local_cap")) {
+        if (value != 0 && value != 1024 && value != 2048) return fail("set_tuning: local_cap must be 0, 1024 or 2048");
+        g_local_cap = value;  // takes effect at the next upload
     } else if (!strcmp(key, "stream_local")) {
         g_stream_local = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "pipe_wgs_per_cu")) {
@@ -476,15 +484,17 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     LocalPlan local;
     bool have_local = false;
     constexpr int line_shift = sizeof(T) == 8 ? 4 : 5;  // 128-byte lines
-    if (g_stream_local && nz > 0 && (g_stream_cap == 0 || g_stream_cap == 2048)) {
-        csr_build_blocks(Ml, rp.data(), 2048, kStreamRowsCap, desc, pieces, long_rows);
-        have_local = csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, 2048, kStreamRowsCap, line_shift,
+    // (1024-entry blocks were tried for small matrices: cant-like 13.2 us against 11.7 us at 2048)
+    const int lcap = g_local_cap ? g_local_cap : 2048;
+    if (g_stream_local && nz > 0 && (g_stream_cap == 0 || g_stream_cap == lcap)) {
+        csr_build_blocks(Ml, rp.data(), lcap, kStreamRowsCap, desc, pieces, long_rows);
+        have_local = csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, lcap, kStreamRowsCap, line_shift,
                                      kLocalLinesMax, desc, local);
     }
     // else: larger stages amortise per-workgroup latency on big matrices; small ones need
     // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
-    m->stream_cap = have_local ? 2048 : (g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048));
-    m->local_cap = 2048;
+    m->stream_cap = have_local ? lcap : (g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048));
+    m->local_cap = lcap;
     // the ring kernel stages at most kRingRows - 1 rows per block; only worth it when such
     // blocks are still (nearly) full, i.e. rows are not tiny
     m->ring_ok = m->stream_cap == kRingCap && Ml > 0 && (double)nz / Ml >= 1.25 * kRingCap / (kRingRows - 1);
@@ -692,14 +702,15 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     const int lgrid = lchunk > 0 ? (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk)
                                                  : m->local_blocks;
                     const size_t lds = std::max((size_t)m->local_cap * sizeof(T), (size_t)m->local_stage_lines * kLineBytes);
-                    if (g_stream_nt)
-                        hipLaunchKernelGGL((csr_stream_local<T, true, 2048>), dim3(lgrid), dim3(kBlock), lds, s,
-                                           m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_ptr,
-                                           m->lcol, (const T *)m->val, x, y);
-                    else
-                        hipLaunchKernelGGL((csr_stream_local<T, false, 2048>), dim3(lgrid), dim3(kBlock), lds, s,
-                                           m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_ptr,
-                                           m->lcol, (const T *)m->val, x, y);
+#define SPMV_LOCAL(NT, CAP)                                                                                   \
+    hipLaunchKernelGGL((csr_stream_local<T, NT, CAP>), dim3(lgrid), dim3(kBlock), lds, s, m->local_blocks, lchunk, \
+                       m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const T *)m->val, x, y)
+                    // streamed-once hint only when the matrix cannot live in the 256 MiB Infinity Cache anyway
+                    // (cant-like, 53 MB: 10.9 us without it, 11.7 us with; fem-large: 160 vs 151 us)
+                    const bool lnt = g_local_nt < 0 ? m->nz * (long long)(sizeof(T) + 2) > (128LL << 20) : g_local_nt != 0;
+                    if (m->local_cap == 1024) { if (lnt) SPMV_LOCAL(true, 1024); else SPMV_LOCAL(false, 1024); }
+                    else { if (lnt) SPMV_LOCAL(true, 2048); else SPMV_LOCAL(false, 2048); }
+#undef SPMV_LOCAL
                 } else if (g_stream_kind == 4 && m->ring_ok) {
                     // loader / consumer ring: one persistent 512-thread workgroup per CU
                     const int wgs = std::max(1, std::min(g_num_cus * g_pipe_wgs_per_cu, m->num_blocks));
@@ -741,6 +752,8 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                         else { if (g_stream_nt) SPMV_WALK(true, 4096, false); else SPMV_WALK(false, 4096, false); }
                     }
 #undef SPMV_WALK
+                } else if (cap == 1024) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 1024, 256);
                 } else if (cap == 2048) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 2048, 256);
                 } else if (cap == 4096 && blk == 512) {
@@ -1212,9 +1225,15 @@ int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y, h
                 const int lchunk = g_stream_xcd < 0 ? (m->local_blocks + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
                 const int lgrid = (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk);
                 const size_t llds = std::max((size_t)2048 * sizeof(double), (size_t)m->local_stage_lines * kLineBytes);
-                hipLaunchKernelGGL((hll_lds_local<double, true, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
-                                   m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
-                                   m->lja, m->AS, x, y);
+                const bool lnt = g_local_nt < 0 ? m->slots * 10 > (128LL << 20) : g_local_nt != 0;
+                if (lnt)
+                    hipLaunchKernelGGL((hll_lds_local<double, true, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
+                                       m->lja, m->AS, x, y);
+                else
+                    hipLaunchKernelGGL((hll_lds_local<double, false, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
+                                       m->lja, m->AS, x, y);
                 break;
             }
             const size_t lds = 32 + ((size_t)m->stage_slots + 2) * sizeof(double);

@@ -27,17 +27,26 @@ for cap in (2048, 4096, 8192):
     d = sp.CsrDevice(M, M, row_ptr, col, val)
     d.set_x(x)
     devs[cap] = d
-info = devs[2048].info()
+set_tuning("stream_cap", 0)
+for lc in (1024, 2048):
+    set_tuning("local_cap", lc)
+    d = sp.CsrDevice(M, M, row_ptr, col, val)
+    d.set_x(x)
+    devs[f"local{lc}"] = d
+set_tuning("local_cap", 0)
+info = devs["local2048"].info()
 algo = info["algo_bytes"]
 print(f"{which}: M={M} nnz={info['nz']} algo_bytes={algo} lanes_per_row={info['lanes_per_row']} "
       f"local_blocks={info['local_blocks']} (prod {info['stream_blocks']}) stage_lines={info['local_stage_lines']} "
       f"lines={info['local_lines']} stream_bytes={info['stream_bytes']}")
 arms = [(f"prod cap={cap} block={blk}", dict(stream_kind=0, stream_block=blk, stream_nt=1, stream_xcd=0), cap, sp.CSR_STREAM)
         for cap, blk in ((2048, 256), (4096, 256), (4096, 512))]
-arms += [("x-window (local) cap=2048", dict(stream_kind=5, stream_nt=1, stream_xcd=0), 2048, sp.CSR_STREAM),
-         ("x-window (local) nt=0", dict(stream_kind=5, stream_nt=0, stream_xcd=0), 2048, sp.CSR_STREAM),
-         ("x-window (local) xcd=-1", dict(stream_kind=5, stream_nt=1, stream_xcd=-1), 2048, sp.CSR_STREAM),
-         ] + [(f"x-window (local) xcd={c}", dict(stream_kind=5, stream_nt=1, stream_xcd=c), 2048, sp.CSR_STREAM)
+arms += [("x-window (local) cap=2048", dict(stream_kind=5, local_nt=1, stream_xcd=0), "local2048", sp.CSR_STREAM),
+         ("x-window (local) cap=1024", dict(stream_kind=5, local_nt=1, stream_xcd=0), "local1024", sp.CSR_STREAM),
+         ("x-window (local) cap=2048 nt=0", dict(stream_kind=5, local_nt=0, stream_xcd=0), "local2048", sp.CSR_STREAM),
+         ("x-window (local) cap=1024 nt=0", dict(stream_kind=5, local_nt=0, stream_xcd=0), "local1024", sp.CSR_STREAM),
+         ("x-window (local) cap=2048 xcd=-1", dict(stream_kind=5, local_nt=1, stream_xcd=-1), "local2048", sp.CSR_STREAM),
+         ] + [(f"x-window (local) cap=2048 xcd={c}", dict(stream_kind=5, local_nt=1, stream_xcd=c), "local2048", sp.CSR_STREAM)
               for c in (8, 64)]
 if os.environ.get("TUNE_ALL"):
     arms += [(f"walk cap={cap}", dict(stream_kind=1, stream_nt=1), cap, sp.CSR_STREAM) for cap in (2048, 4096)]
