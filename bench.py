@@ -311,11 +311,13 @@ def main():
     log(f"[rank {rank}] {wl['name']}: M={M} nnz={nnz_total} built in {time.time() - t0:.1f}s on {dev_name}")
 
     hll_mode = args.workload == "cant_hll"
-    if hll_mode and world > 1:
-        raise SystemExit("the HLL workload is single-GPU (BASELINE configs[2])")
+    if hll_mode:
+        # HLL splits on hack boundaries with the reference's hack partitioner
+        hack_bounds = sp.partition_hacks(wl["hll"], world)
+        bounds = sp.hack_bounds_to_rows(hack_bounds, M)
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     if hll_mode:
-        dev = sp.HllDevice(wl["hll"])
+        dev = sp.HllDevice(wl["hll"], int(hack_bounds[rank]), int(hack_bounds[rank + 1]))
         variant = sp.HLL_AUTO if args.variant == "auto" else sp.HLL_VARIANTS[args.variant]
         vb = 8
     else:
@@ -416,7 +418,7 @@ def main():
         ms_xchg = np.array([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)])
 
     stats = torch.tensor([wall, float(np.mean(ms_kernel)), float(np.mean(ms_xchg)) if ms_xchg is not None else 0.0,
-                          float(info["algo_bytes"]), float(info["nz"]),
+                          float(info["algo_bytes"]), float(info["slots"] if hll_mode else info["nz"]),
                           float(info.get("stream_bytes", 0))], dtype=torch.float64)
     if world > 1:
         if exchange != "gloo-host":
@@ -436,8 +438,11 @@ def main():
         if args.workload == "nlpkkt" and not args.mtx:
             grid = tuple(int(v) for v in args.grid.split(",")) if args.grid else synth.KKT_GRID
             _, rp_all, col_all, val_all = synth.kkt_like(grid, 2)
+        elif args.workload in ("cant", "cant_hll") and not args.mtx:
+            grid = tuple(int(v) for v in args.grid.split(",")) if args.grid else synth.FEM_GRID
+            _, rp_all, col_all, val_all = synth.fem_like(grid, 1)
         else:
-            raise SystemExit("--check is implemented for the synthetic nlpkkt workload")
+            raise SystemExit("--check is implemented for the synthetic nlpkkt / cant workloads")
         y_ref = Oracle().csr_serial(rp_all, col_all, val_all, np.ones(N))
         err = float(np.max(np.abs(y_gpu - y_ref)) / max(np.max(np.abs(y_ref)), 1e-300))
         log(f"[rank {rank}] check: max|y - y_ref| / max|y_ref| = {err:.3e} over {M} rows (rows {r0}..{r1} computed here)")
@@ -455,10 +460,10 @@ def main():
         # the STREAM variant runs csr_stream_local (x lines staged in LDS, 16-bit local columns)
         # when upload found a plan for the matrix, else csr_stream (gathers)
         stream_name = "csr_stream_local" if (not hll_mode and info.get("local_blocks", 0) > 0) else "csr_stream"
-        kernel_name = ("hll_lds" if hll_mode else
+        kernel_name = (("hll_lds_local" if info.get("local_blocks", 0) > 0 else "hll_lds") if hll_mode else
                        {0: stream_name, 1: "csr_thread_row", 2: "csr_vector<64,2>", 3: "csr_vector<L,1>",
                         4: stream_name}[variant if variant else info["auto_variant"]])
-        moved = float(per_rank[slow, 5]) if kernel_name == "csr_stream_local" else float(per_rank[slow, 3])
+        moved = float(per_rank[slow, 5]) if kernel_name.endswith("_local") else float(per_rank[slow, 3])
         result = {
             "metric": "SpMV GFLOP/s (2*nnz flops / step time); achieved HBM GB/s and % of 8 TB/s alongside",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -145,6 +145,10 @@ int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, int z
 /* ---- HLL --------------------------------------------------------------- */
 /* total_rows = the matrix' M (the last hack may hold fewer than 32 rows). */
 int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out);
+/* One rank's share: hacks [hack0, hack1) = rows [32 hack0, min(32 hack1, total_rows)).  y keeps the
+ * full length; the kernels write this handle's rows (HLL is split on hack boundaries). */
+int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
+                             spmv_hll_dev **out);
 /* build the HLL slab ON THE DEVICE from a resident whole fp64 CSR matrix
  * (per-hack maximum, H-sized offset scan on the host, fill kernel); same slab as
  * convert_to_hll + spmv_hip_hll_upload give when no column repeats inside a row. */
@@ -169,6 +173,9 @@ int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, int z
  * output: bounds[0..parts] with bounds[0] = 0, bounds[parts] = M; a part may
  * be empty (bounds[p] == bounds[p+1]).  Pure host code, no device needed. */
 int spmv_hip_partition_rows(int M, const int *row_ptr, int parts, int *bounds);
+/* The same for HLL with the reference's hack partitioner (prepare_thread_distribution_hll,
+ * src/hll_matrix.c:410-540, weight = padded slots): bounds[parts + 1] are HACK indices. */
+int spmv_hip_partition_hacks(const HLLMatrix *hll, int parts, int *bounds);
 
 /* RCCL communicator over the GPUs of one node.  Rank 0 creates the id
  * (SPMV_COMM_ID_BYTES opaque bytes) and hands it to the other processes by
@@ -186,6 +193,9 @@ int spmv_hip_comm_allgatherv(void *d_y, const int *bounds, int value_bytes, void
  * the library-owned y, both on the library stream, events around each part.
  * ms_kernel / ms_exchange receive `iters` values (either may be NULL). */
 int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *bounds, int warmup, int iters,
+                           float *ms_kernel, float *ms_exchange);
+/* HLL twin; bounds are ROW bounds (32 x the hack bounds of spmv_hip_partition_hacks, last = M) */
+int spmv_hip_hll_step_time(spmv_hll_dev *m, int variant, const int *bounds, int warmup, int iters,
                            float *ms_kernel, float *ms_exchange);
 
 #ifdef __cplusplus

@@ -133,7 +133,8 @@ struct spmv_csr_dev {
 };
 
 struct spmv_hll_dev {
-    int M = 0, N = 0, hacks = 0;
+    int M = 0, N = 0, hacks = 0;  // rows / hacks HELD by this handle
+    int M_total = 0, row0 = 0;    // rows of the whole matrix (length of y), first global row (multiple of 32)
     long long nz_hint = 0;
     long long slots = 0;
     long long *hack_off = nullptr;  // [hacks + 1]
@@ -958,7 +959,10 @@ long long hll_offsets(int total_rows, const std::vector<int> &mz, std::vector<lo
 
 // workgroup windows, small arrays and vectors of a handle whose JA / AS are already on the device
 int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<long long> &off,
-                      const std::vector<int> &mz, long long true_slots, bool upload_maxnz, const int *ja_host) {
+                      const std::vector<int> &mz, long long true_slots, bool upload_maxnz, const int *ja_host,
+                      int matrix_rows = -1, int row0 = 0) {
+    m->M_total = matrix_rows < 0 ? total_rows : matrix_rows;
+    m->row0 = row0;
     const int H = (int)mz.size();
     // like the CSR stream kernel: larger stages for matrices that have plenty of work
     const int cap = true_slots >= (16LL << 20) ? kHllCap : kHllCap / 2;
@@ -978,9 +982,9 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
     if (!rc) {
         const size_t x_bytes = std::max<size_t>((size_t)N, 1) * sizeof(double) + kLineBytes;  // whole-line reads
         hipError_t e = hipMalloc((void **)&m->x, x_bytes);
-        if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)m->M_total, 1) * sizeof(double));
         if (e == hipSuccess) e = hipMemset(m->x, 0, x_bytes);
-        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)total_rows, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)m->M_total, 1) * sizeof(double));
         if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
     }
     m->device_bytes = off.size() * 8 + mz.size() * 4 + ((size_t)off[H] + kPad) * 12 + hdesc.size() * 16 +
@@ -1010,39 +1014,48 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
 
 }  // namespace
 
-extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
+// Hacks [hack0, hack1) of the matrix, i.e. rows [32 hack0, min(32 hack1, total_rows)): one
+// rank's share under the reference's hack partitioner (prepare_thread_distribution_hll,
+// src/hll_matrix.c:410-540); y stays full length, the kernels write this handle's rows.
+extern "C" int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
+                                        spmv_hll_dev **out) {
     if (need_device()) return -1;
     if (!hll || !out) return fail("hll_upload: NULL argument");
     *out = nullptr;
     if ((unsigned long long)N * 8 >= (1ull << 32))
         return fail("hll_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
-    const int H = hll->num_blocks;
-    if (H != (total_rows + kHack - 1) / kHack)
-        return fail("hll_upload: %d hacks do not match %d rows", H, total_rows);
+    const int Hall = hll->num_blocks;
+    if (Hall != (total_rows + kHack - 1) / kHack)
+        return fail("hll_upload: %d hacks do not match %d rows", Hall, total_rows);
+    if (hack0 < 0 || hack1 < hack0 || hack1 > Hall)
+        return fail("hll_upload: bad hack range [%d, %d) of %d", hack0, hack1, Hall);
+    const int H = hack1 - hack0;
+    const int row0 = hack0 * kHack;
+    const int rows = std::min(hack1 * kHack, total_rows) - std::min(row0, total_rows);
 
     std::vector<int> mz((size_t)H, 0);
     for (int h = 0; h < H; ++h) {
-        const ELLPACKBlock *b = &hll->blocks[h];
-        const int expect = (h == H - 1) ? total_rows - h * kHack : kHack;
-        if (b->M != expect) return fail("hll_upload: hack %d holds %d rows, expected %d", h, b->M, expect);
+        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
+        const int expect = (hack0 + h == Hall - 1) ? total_rows - (hack0 + h) * kHack : kHack;
+        if (b->M != expect) return fail("hll_upload: hack %d holds %d rows, expected %d", hack0 + h, b->M, expect);
         if (b->MAXNZ < 0 || (b->MAXNZ > 0 && (!b->JA || !b->AS)))
-            return fail("hll_upload: hack %d is malformed", h);
+            return fail("hll_upload: hack %d is malformed", hack0 + h);
         mz[h] = b->MAXNZ;
         const long long s = (long long)b->M * b->MAXNZ;
         for (long long k = 0; k < s; ++k)
             if ((unsigned)b->JA[k] >= (unsigned)N)
-                return fail("hll_upload: column index %d in hack %d is outside [0, %d)", b->JA[k], h, N);
+                return fail("hll_upload: column index %d in hack %d is outside [0, %d)", b->JA[k], hack0 + h, N);
     }
     std::vector<long long> off;
     long long true_slots = 0;
-    const long long S = hll_offsets(total_rows, mz, off, true_slots);
+    const long long S = hll_offsets(rows, mz, off, true_slots);
     if (S > (1LL << 40)) return fail("hll_upload: %lld padded slots is unreasonable", S);
 
     // pack every hack into one flat pair of host arrays, then two copies
     std::vector<int> ja((size_t)S + kPad, 0);
     std::vector<double> as((size_t)S + kPad, 0.0);
     for (int h = 0; h < H; ++h) {
-        const ELLPACKBlock *b = &hll->blocks[h];
+        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
         const size_t s = (size_t)b->M * b->MAXNZ;
         if (!s) continue;
         memcpy(&ja[(size_t)off[h]], b->JA, s * sizeof(int));
@@ -1052,7 +1065,7 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
     if (!m) return fail("hll_upload: out of host memory");
     int rc = upload_array(&m->JA, ja.data(), ja.size(), 0);
     if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
-    if (!rc) rc |= hll_finish_handle(m, total_rows, N, off, mz, true_slots, true, ja.data());
+    if (!rc) rc |= hll_finish_handle(m, rows, N, off, mz, true_slots, true, ja.data(), total_rows, row0);
     if (rc) {
         spmv_hip_hll_free(m);
         return -1;
@@ -1061,14 +1074,21 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
     return 0;
 }
 
+extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
+    if (!hll) return fail("hll_upload: NULL argument");
+    return spmv_hip_hll_upload_part(hll, total_rows, N, 0, hll->num_blocks, out);
+}
+
 // HLL built on the device from a resident CSR matrix (whole matrix, fp64).
 extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out) {
     if (need_device()) return -1;
     if (!csr || !out) return fail("hll_from_csr: NULL argument");
     *out = nullptr;
-    if (csr->value_bytes != 8 || csr->row0 != 0 || csr->M_local != csr->M_total)
-        return fail("hll_from_csr: needs a whole fp64 CSR matrix");
-    const int M = csr->M_total, N = csr->N, H = (M + kHack - 1) / kHack;
+    // a row block works when it starts on a hack boundary and ends on one (or at the last row)
+    if (csr->value_bytes != 8 || csr->row0 % kHack != 0 ||
+        ((csr->row0 + csr->M_local) % kHack != 0 && csr->row0 + csr->M_local != csr->M_total))
+        return fail("hll_from_csr: needs a whole fp64 CSR matrix (or a row block cut on hack boundaries)");
+    const int M = csr->M_local, N = csr->N, H = (M + kHack - 1) / kHack;
     spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
     if (!m) return fail("hll_from_csr: out of host memory");
     std::vector<int> mz((size_t)H, 0);
@@ -1109,7 +1129,8 @@ extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out
             e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
         }
-        rc = hll_finish_handle(m, M, N, off, mz, true_slots, false, ja_host.empty() ? nullptr : ja_host.data());
+        rc = hll_finish_handle(m, M, N, off, mz, true_slots, false, ja_host.empty() ? nullptr : ja_host.data(),
+                               csr->M_total, csr->row0);
     } while (0);
     if (rc) {
         spmv_hip_hll_free(m);
@@ -1154,7 +1175,9 @@ extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
 extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     if (!m || !out) return fail("hll_info: NULL argument");
     memset(out, 0, sizeof *out);
-    out->M_local = out->M_total = m->M;
+    out->M_local = m->M;
+    out->M_total = m->M_total;
+    out->row0 = m->row0;
     out->N = m->N;
     out->value_bytes = 8;
     out->auto_variant = m->auto_variant;
@@ -1189,7 +1212,7 @@ extern "C" int spmv_hip_hll_get_y(spmv_hll_dev *m, double *y_host) {
     if (need_device()) return -1;
     if (!m || !y_host) return fail("hll_get_y: NULL argument");
     HIP_TRY(hipStreamSynchronize(g_stream));
-    HIP_TRY(hipMemcpy(y_host, m->y, (size_t)m->M * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(y_host, m->y, (size_t)m->M_total * 8, hipMemcpyDeviceToHost));  // whole y, as for CSR
     return 0;
 }
 
@@ -1202,8 +1225,9 @@ void launch_hll_vector(const spmv_hll_dev *m, const double *x, double *y, hipStr
                        m->M, m->hack_off, m->maxnz, m->JA, m->AS, x, y);
 }
 
-int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y, hipStream_t s) {
+int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_full, hipStream_t s) {
     if (m->M == 0) return 0;
+    double *y = y_full + m->row0;  // the kernels number this handle's rows from 0
     if (variant == SPMV_HLL_AUTO) variant = m->auto_variant;
     switch (variant) {
         case SPMV_HLL_THREAD_ROW:
@@ -1276,12 +1300,30 @@ extern "C" int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int i
     return time_loop(
         warmup, iters, ms_each, [&] { return hll_launch(m, variant, m->x, m->y, g_stream); },
         [&]() -> int {
-            if (zero_y) HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M * 8, g_stream));
+            if (zero_y) HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M_total * 8, g_stream));
             return 0;
         });
 }
 
 // ------------------------------------------------------------- multi-GPU
+// Hack ranges for `parts` ranks by the reference's HLL partitioner (K8: greedy over hacks,
+// weight = padded slots; src/hll_matrix.c:410-540).  bounds[p] .. bounds[p + 1] are HACK indices.
+extern "C" int spmv_hip_partition_hacks(const HLLMatrix *hll, int parts, int *bounds) {
+    if (!hll || parts <= 0 || !bounds || hll->num_blocks < 0) return fail("partition_hacks: bad arguments");
+    const int H = hll->num_blocks;
+    for (int p = 0; p <= parts; ++p) bounds[p] = H;
+    bounds[0] = 0;
+    if (H == 0) return 0;
+    int *start = nullptr, *end = nullptr;
+    const int got = prepare_thread_distribution_hll(hll, parts, &start, &end);
+    for (int p = 0; p < got; ++p) bounds[p + 1] = (p == got - 1) ? H : start[p + 1];
+    for (int p = got + 1; p <= parts; ++p) bounds[p] = H;
+    if (got == 0) bounds[1] = H;
+    free(start);
+    free(end);
+    return 0;
+}
+
 extern "C" int spmv_hip_partition_rows(int M, const int *row_ptr, int parts, int *bounds) {
     if (M < 0 || parts <= 0 || !bounds || (M > 0 && !row_ptr)) return fail("partition_rows: bad arguments");
     for (int p = 0; p <= parts; ++p) bounds[p] = M;
@@ -1352,19 +1394,21 @@ extern "C" int spmv_hip_comm_allgatherv(void *d_y, const int *bounds, int value_
     return 0;
 }
 
-extern "C" int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *bounds, int warmup,
-                                      int iters, float *ms_kernel, float *ms_exchange) {
-    if (need_device()) return -1;
-    if (!m || !bounds) return fail("csr_step_time: NULL argument");
-    if (iters <= 0) return fail("csr_step_time: iters must be > 0");
+namespace {
+
+// one step = this rank's kernel, then the all-gatherv of y (when a communicator exists)
+template <typename Launch>
+int step_loop(void *y, int value_bytes, const int *bounds, int warmup, int iters, float *ms_kernel,
+              float *ms_exchange, Launch launch) {
+    if (iters <= 0) return fail("step_time: iters must be > 0");
     std::vector<hipEvent_t> ev((size_t)iters * 3);
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
     int rc = 0;
     for (int i = -warmup; i < iters && !rc; ++i) {
         if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i], g_stream));
-        rc = csr_launch_any(m, variant, m->x, m->y, g_stream);
+        rc = launch();
         if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 1], g_stream));
-        if (!rc && g_comm) rc = spmv_hip_comm_allgatherv(m->y, bounds, m->value_bytes, g_stream);
+        if (!rc && g_comm) rc = spmv_hip_comm_allgatherv(y, bounds, value_bytes, g_stream);
         if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 2], g_stream));
     }
     if (!rc) {
@@ -1379,4 +1423,23 @@ extern "C" int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *b
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *bounds, int warmup,
+                                      int iters, float *ms_kernel, float *ms_exchange) {
+    if (need_device()) return -1;
+    if (!m || !bounds) return fail("csr_step_time: NULL argument");
+    return step_loop(m->y, m->value_bytes, bounds, warmup, iters, ms_kernel, ms_exchange,
+                     [&] { return csr_launch_any(m, variant, m->x, m->y, g_stream); });
+}
+
+// HLL twin: bounds are ROW bounds (32 x the hack bounds of spmv_hip_partition_hacks, the last one M)
+extern "C" int spmv_hip_hll_step_time(spmv_hll_dev *m, int variant, const int *bounds, int warmup,
+                                      int iters, float *ms_kernel, float *ms_exchange) {
+    if (need_device()) return -1;
+    if (!m || !bounds) return fail("hll_step_time: NULL argument");
+    return step_loop(m->y, 8, bounds, warmup, iters, ms_kernel, ms_exchange,
+                     [&] { return hll_launch(m, variant, m->x, m->y, g_stream); });
 }

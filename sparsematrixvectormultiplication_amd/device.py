@@ -169,20 +169,35 @@ class HllDevice(_Handle):
 
     _free = "spmv_hip_hll_free"
 
-    def __init__(self, hll: HllHost = None):
+    def __init__(self, hll: HllHost = None, hack0=0, hack1=None):
+        """The whole matrix, or hacks [hack0, hack1) of it (one rank's share)."""
         super().__init__()
         if hll is not None:
-            _check(nat.lib().spmv_hip_hll_upload(C.byref(hll.c), int(hll.M), int(hll.N),
-                                                 C.byref(self.h)), "spmv_hip_hll_upload")
+            hack1 = hll.num_blocks if hack1 is None else hack1
+            _check(nat.lib().spmv_hip_hll_upload_part(C.byref(hll.c), int(hll.M), int(hll.N), int(hack0),
+                                                      int(hack1), C.byref(self.h)), "spmv_hip_hll_upload_part")
             self.M, self.N = hll.M, hll.N
+
+    def step_time(self, row_bounds, variant=HLL_AUTO, warmup=5, iters=95):
+        """Multi-GPU step (SpMV on this rank's hacks + all-gatherv of y): kernel and exchange ms."""
+        b = np.ascontiguousarray(row_bounds, dtype=np.int32)
+        mk, mx = np.zeros(iters, np.float32), np.zeros(iters, np.float32)
+        _check(nat.lib().spmv_hip_hll_step_time(self.h, int(variant), b.ctypes.data_as(nat.c_int_p),
+                                                int(warmup), int(iters), mk.ctypes.data_as(nat.c_float_p),
+                                                mx.ctypes.data_as(nat.c_float_p)), "hll_step_time")
+        return mk, mx
 
     @classmethod
     def from_csr_device(cls, csr: "CsrDevice"):
         """HLL built on the GPU from a resident CSR matrix (spmv_hip_hll_from_csr)."""
         self = cls()
         _check(nat.lib().spmv_hip_hll_from_csr(csr.h, C.byref(self.h)), "spmv_hip_hll_from_csr")
-        self.M, self.N = csr.M, csr.N
+        self.M, self.N = csr.info()["M_total"], csr.N
         return self
+
+    def run_on(self, d_x: int, d_y: int, variant=HLL_AUTO, stream: int = 0):
+        _check(nat.lib().spmv_hip_hll_run_on(self.h, int(variant), C.c_void_p(d_x), C.c_void_p(d_y),
+                                             C.c_void_p(stream)), "hll_run_on")
 
     x_ptr = property(lambda s: nat.lib().spmv_hip_hll_x_ptr(s.h) or 0)
     y_ptr = property(lambda s: nat.lib().spmv_hip_hll_y_ptr(s.h) or 0)

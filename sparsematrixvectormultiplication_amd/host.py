@@ -246,6 +246,19 @@ def partition_rows(row_ptr, parts):
     return bounds
 
 
+def partition_hacks(hll: "HllHost", parts):
+    """Hack bounds [0 = b0 <= ... <= b_parts = num_blocks] for `parts` GPUs (reference K8 greedy)."""
+    bounds = np.zeros(parts + 1, dtype=np.int32)
+    if nat.lib().spmv_hip_partition_hacks(C.byref(hll.c), int(parts), _ip(bounds)) != 0:
+        raise ValueError(nat.lib().spmv_hip_last_error().decode())
+    return bounds
+
+
+def hack_bounds_to_rows(hack_bounds, M):
+    """Row bounds of a hack partition: 32 x the hack bounds, clipped to M."""
+    return np.minimum(np.asarray(hack_bounds, dtype=np.int64) * HACK_SIZE, M).astype(np.int32)
+
+
 def compute_difference_metrics(ref, res, abs_tol=1e-5, rel_tol=1e-4):
     """CPU-build measure; the reference calls it with (1e-5, 1e-4) (main.c:145)."""
     ref = np.ascontiguousarray(ref, dtype=np.float64)

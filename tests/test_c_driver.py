@@ -75,6 +75,19 @@ def test_bench_row_partitioned_two_ranks_sharing_the_gpu(gpu):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["parallelism"] == "row-block x2"
     assert proc.stderr.count("check: max|y - y_ref|") == 2
+    # the HLL workload on two ranks: hack-aligned shares (reference's hack partitioner)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "cant_hll", "--grid", "5,5,40",
+           "--exchange", "gloo-host", "--check", "--no-cpu-baseline"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and "HLL" in out["config"]["workload"] and out["value"] > 0
+    assert proc.stderr.count("check: max|y - y_ref|") == 2
 
 
 @pytest.mark.gpu

@@ -422,7 +422,7 @@ def test_hll_from_csr_rejects_row_blocks_and_fp32(gpu):
     rng = np.random.default_rng(5)
     row_ptr, col, val = random_csr(rng, 200, 200, 5, 9, 0.0)
     with sp.CsrDevice(200, 200, row_ptr, col, val, row0=50, row1=150) as part:
-        with pytest.raises(RuntimeError, match="whole fp64"):
+        with pytest.raises(RuntimeError, match="whole fp64"):   # not cut on hack boundaries
             sp.HllDevice.from_csr_device(part)
     with sp.CsrDevice(200, 200, row_ptr, col, val.astype(np.float32)) as f32:
         with pytest.raises(RuntimeError, match="whole fp64"):
@@ -590,3 +590,54 @@ def test_hll_x_window_kernel_matches_oracle(gpu, oracle, mean, band, empty, far)
             assert built.spmv(x, sp.HLL_LDS).tobytes() == first.tobytes()
     finally:
         set_tuning("stream_kind", -1)
+
+
+# ------------------------------------------- HLL hack ranges (multi-GPU shares)
+def test_hll_hack_range_handles_cover_the_matrix(gpu, oracle):
+    """HLL splits on hack boundaries.  Three handles holding the K8 partition's
+    hack ranges each write only their rows of a full-length y; together they give the
+    whole product.  The same ranges built on the device from 32-aligned CSR row blocks give
+    the same bits; a row block that is not cut on a hack boundary is refused."""
+    from _util import banded_csr
+    rng = np.random.default_rng(91)
+    for (M, N, gen) in ((1000, 1100, "banded"), (333, 2000, "random")):
+        if gen == "banded":
+            row_ptr, col, val = banded_csr(rng, M, N, 20, 120, 0.05)
+        else:
+            row_ptr, col, val = random_csr(rng, M, N, 15, 60, 0.1)
+        r, c, v = coo_from_csr(row_ptr, col, val, rng)
+        hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, N, r, c, v))
+        x = rng.uniform(-1, 1, N)
+        y_ref = oracle.csr_serial(row_ptr, col, val, x)
+        hb = sp.partition_hacks(hll, 3)
+        rb = sp.hack_bounds_to_rows(hb, M)
+        assert hb[0] == 0 and hb[-1] == hll.num_blocks
+        y_all = np.full(M, np.nan)
+        for p in range(3):
+            with sp.HllDevice(hll, int(hb[p]), int(hb[p + 1])) as part:
+                info = part.info()
+                assert (info["row0"], info["M_local"], info["M_total"]) == (rb[p], rb[p + 1] - rb[p], M)
+                for vname, variant in HLL_V:
+                    part.set_x(x)
+                    sp.lib().spmv_hip_memset(part.y_ptr, 0xFF, M * 8)
+                    part.run(variant)
+                    y = part.get_y()
+                    lo, hi = rb[p], rb[p + 1]
+                    assert np.all(np.isnan(y[:lo])) and np.all(np.isnan(y[hi:])), f"{vname}: wrote outside its rows"
+                    assert_parity(y[lo:hi], y_ref[lo:hi], row_ptr[lo:hi + 1] - row_ptr[lo],
+                                  col[row_ptr[lo]:row_ptr[hi]], val[row_ptr[lo]:row_ptr[hi]], x,
+                                  what=f"hack range {p} {vname}")
+                y_all[lo:hi] = y[lo:hi]
+                # same range from the resident CSR row block
+                if hi > lo:
+                    with sp.CsrDevice(M, N, row_ptr, col, val, row0=int(lo), row1=int(hi)) as cpart, \
+                            sp.HllDevice.from_csr_device(cpart) as built:
+                        assert built.info()["row0"] == lo and built.info()["slots"] == info["slots"]
+                        built.set_x(x)
+                        built.run(sp.HLL_LDS)
+                        part.run(sp.HLL_LDS)
+                        assert built.get_y()[lo:hi].tobytes() == part.get_y()[lo:hi].tobytes()
+        assert not np.any(np.isnan(y_all))
+    with sp.CsrDevice(M, N, row_ptr, col, val, row0=5, row1=200) as odd:
+        with pytest.raises(RuntimeError, match="hack boundaries"):
+            sp.HllDevice.from_csr_device(odd)

@@ -103,3 +103,21 @@ def test_partition_invariants():
             bounds = sp.partition_rows(row_ptr, T)
             assert bounds[0] == 0 and bounds[-1] == M and np.all(np.diff(bounds) >= 0)
             assert len(bounds) == T + 1
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("parts", [1, 2, 3, 8])
+def test_partition_hacks_follows_the_reference_hack_partitioner(name, parts):
+    """spmv_hip_partition_hacks = prepare_thread_distribution_hll (K8) turned into contiguous,
+    covering hack bounds: same chunk starts, trailing parts empty."""
+    pre = sp.read_matrix_market(golden_path(name))
+    hll = sp.convert_to_hll(pre)
+    bounds = sp.partition_hacks(hll, parts)
+    H = hll.num_blocks
+    assert bounds[0] == 0 and bounds[-1] == H and np.all(np.diff(bounds) >= 0)
+    starts, ends = sp.prepare_thread_distribution_hll(hll, parts)
+    for p in range(len(starts)):
+        assert bounds[p] <= starts[p] and (p == 0 or bounds[p] == starts[p])
+    assert np.all(bounds[len(starts) + 1:] == H) if len(starts) else bounds[1] == H
+    rows = sp.hack_bounds_to_rows(bounds, pre.M)
+    assert rows[-1] == pre.M and np.all((rows % 32 == 0) | (rows == pre.M))
