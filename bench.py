@@ -249,7 +249,10 @@ def side_measurement(sp, synth, which, steps, warmup):
                 ms = dev.time(variant, warmup, steps, zero_y=True)
                 out[name] = {"gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
                              "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
-                             "us": round(float(ms.mean()) * 1e3, 2)}
+                             "us": round(float(ms.mean()) * 1e3, 2),
+                             "us_median": round(float(np.median(ms)) * 1e3, 2)}
+            # the launch-bound case: 20 launches replayed from one hipGraph, wall time per SpMV
+            out["stream"]["us_per_spmv_graph_replay"] = round(dev.time_graph(sp.CSR_STREAM, 20, 10) * 1e3, 2)
         out["stream"]["kernel"] = "csr_stream_local" if info["local_blocks"] else "csr_stream"
         return {"workload": "cant-like fp64 CSR (M=62451, nnz=%d; Infinity-Cache resident)" % nnz,
                 "algo_bytes": info["algo_bytes"], **out}

@@ -149,6 +149,12 @@ int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_de
  * full length; the kernels write this handle's rows (HLL is split on hack boundaries). */
 int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
                              spmv_hll_dev **out);
+/* `iters` launches captured once into a hipGraph and replayed `replays` times (after one warm-up
+ * replay): mean time per SpMV with the per-launch host work out of the way -- the number that
+ * matters for launch-bound matrices (cant: ~11 us kernel).  Also for HLL below. */
+int spmv_hip_csr_time_graph(spmv_csr_dev *m, int variant, int iters, int replays, float *ms_per_iter);
+int spmv_hip_hll_time_graph(spmv_hll_dev *m, int variant, int iters, int replays, float *ms_per_iter);
+
 /* build the HLL slab ON THE DEVICE from a resident whole fp64 CSR matrix
  * (per-hack maximum, H-sized offset scan on the host, fill kernel); same slab as
  * convert_to_hll + spmv_hip_hll_upload give when no column repeats inside a row. */

@@ -165,6 +165,8 @@ _PROTOTYPES = {
                                          c_float_p]),
     "spmv_hip_hll_upload": (C.c_int, [C.POINTER(HLLMatrix), C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
+    "spmv_hip_csr_time_graph": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]),
+    "spmv_hip_hll_time_graph": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]),
     "spmv_hip_hll_x_ptr": (C.c_void_p, [C.c_void_p]),
     "spmv_hip_hll_y_ptr": (C.c_void_p, [C.c_void_p]),
     "spmv_hip_hll_from_csr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -848,6 +848,55 @@ extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int i
         });
 }
 
+namespace {
+
+// `iters` back-to-back launches captured once into a hipGraph and replayed `replays` times:
+// what a launch-bound loop (small matrices: an 11 us kernel against ~6 us of per-launch host
+// work) costs per SpMV when the host is out of the way.  ms_per_iter = mean over the replays.
+template <typename Launch>
+int graph_loop(int iters, int replays, float *ms_per_iter, Launch launch) {
+    if (iters <= 0 || replays <= 0 || !ms_per_iter) return fail("time_graph: bad arguments");
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    hipError_t e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return fail("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+    for (int i = 0; i < iters && !rc; ++i) rc = launch();
+    e = hipStreamEndCapture(g_stream, &graph);
+    if (!rc && e != hipSuccess) rc = fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    if (!rc) {
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) rc = fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipGraphLaunch(exec, g_stream);  // warm-up replay
+        if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
+        for (int r = 0; r < replays && e == hipSuccess; ++r) e = hipGraphLaunch(exec, g_stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail("graph replay failed: %s", hipGetErrorString(e));
+        else *ms_per_iter = ms / ((float)replays * (float)iters);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_time_graph(spmv_csr_dev *m, int variant, int iters, int replays, float *ms_per_iter) {
+    if (need_device()) return -1;
+    if (!m) return fail("csr_time_graph: NULL handle");
+    return graph_loop(iters, replays, ms_per_iter, [&] { return csr_launch_any(m, variant, m->x, m->y, g_stream); });
+}
+
 // ----------------------------------------------------------------- HLL
 namespace {
 
@@ -1303,6 +1352,12 @@ extern "C" int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int i
             if (zero_y) HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M_total * 8, g_stream));
             return 0;
         });
+}
+
+extern "C" int spmv_hip_hll_time_graph(spmv_hll_dev *m, int variant, int iters, int replays, float *ms_per_iter) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_time_graph: NULL handle");
+    return graph_loop(iters, replays, ms_per_iter, [&] { return hll_launch(m, variant, m->x, m->y, g_stream); });
 }
 
 // ------------------------------------------------------------- multi-GPU

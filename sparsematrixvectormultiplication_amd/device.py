@@ -153,6 +153,13 @@ class CsrDevice(_Handle):
                "csr_time")
         return ms
 
+    def time_graph(self, variant=CSR_AUTO, iters=20, replays=10) -> float:
+        """ms per SpMV when `iters` launches are replayed from one hipGraph."""
+        ms = C.c_float(0)
+        _check(nat.lib().spmv_hip_csr_time_graph(self.h, int(variant), int(iters), int(replays), C.byref(ms)),
+               "csr_time_graph")
+        return float(ms.value)
+
     def step_time(self, bounds, variant=CSR_AUTO, warmup=5, iters=95):
         """Multi-GPU step (SpMV + all-gatherv of y): per-step kernel and exchange ms."""
         b = np.ascontiguousarray(bounds, dtype=np.int32)
@@ -177,6 +184,12 @@ class HllDevice(_Handle):
             _check(nat.lib().spmv_hip_hll_upload_part(C.byref(hll.c), int(hll.M), int(hll.N), int(hack0),
                                                       int(hack1), C.byref(self.h)), "spmv_hip_hll_upload_part")
             self.M, self.N = hll.M, hll.N
+
+    def time_graph(self, variant=HLL_AUTO, iters=20, replays=10) -> float:
+        ms = C.c_float(0)
+        _check(nat.lib().spmv_hip_hll_time_graph(self.h, int(variant), int(iters), int(replays), C.byref(ms)),
+               "hll_time_graph")
+        return float(ms.value)
 
     def step_time(self, row_bounds, variant=HLL_AUTO, warmup=5, iters=95):
         """Multi-GPU step (SpMV on this rank's hacks + all-gatherv of y): kernel and exchange ms."""

@@ -641,3 +641,25 @@ def test_hll_hack_range_handles_cover_the_matrix(gpu, oracle):
     with sp.CsrDevice(M, N, row_ptr, col, val, row0=5, row1=200) as odd:
         with pytest.raises(RuntimeError, match="hack boundaries"):
             sp.HllDevice.from_csr_device(odd)
+
+
+def test_graph_replayed_timing_leaves_the_result_intact(gpu, oracle):
+    """spmv_hip_*_time_graph: a captured batch of launches replayed from a hipGraph; y after the
+    replays is the same SpMV result, the per-SpMV time is positive and not above the
+    event-timed launch loop by much (it removes host work, it cannot add kernel time)."""
+    from _util import banded_csr
+    rng = np.random.default_rng(123)
+    M = N = 20000
+    row_ptr, col, val = banded_csr(rng, M, N, 40, 200)
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_serial(row_ptr, col, val, x)
+    with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
+        dev.set_x(x)
+        t_graph = dev.time_graph(sp.CSR_STREAM, 10, 5)
+        assert_parity(dev.get_y(), y_ref, row_ptr, col, val, x, what="after graph replay")
+        t_loop = float(dev.time(sp.CSR_STREAM, 3, 20, zero_y=False).mean())
+        assert 0 < t_graph < 5 * t_loop + 0.05
+        with sp.HllDevice.from_csr_device(dev) as h:
+            h.set_x(x)
+            assert h.time_graph(sp.HLL_LDS, 10, 5) > 0
+            assert_parity(h.get_y(), y_ref, row_ptr, col, val, x, what="hll after graph replay")
