@@ -330,17 +330,20 @@ namespace {
 // (counted from the even entry at or below its first) fit `cap`.  A row that
 // cannot be staged is cut into pieces {row, first entry, end entry, slot} whose
 // partial sums csr_long_finish adds up per long row {row, first slot, pieces, 0}.
+// `split` (optional, one byte per row) marks rows that go to the split-row kernels whatever their
+// length: rows the x-window plan cannot take (more x lines than a block may list).
 void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<int4> &desc,
-                      std::vector<int4> &pieces, std::vector<int4> &long_rows) {
+                      std::vector<int4> &pieces, std::vector<int4> &long_rows,
+                      const std::vector<unsigned char> *split = nullptr) {
     desc.clear();
     pieces.clear();
     long_rows.clear();
+    auto is_long = [&](int row) { return rp[row + 1] - rp[row] > cap - 3 || (split && (*split)[row]); };
     int r = 0;
     while (r < M) {
         const int n0 = rp[r];
-        const int len = rp[r + 1] - n0;
         const int base = n0 & kBaseMask;
-        if (len > cap - 3) {
+        if (is_long(r)) {
             const int first_slot = (int)pieces.size();
             for (int p = n0; p < rp[r + 1]; p += kLongPiece)
                 pieces.push_back(int4{r, p, std::min(p + kLongPiece, rp[r + 1]), (int)pieces.size()});
@@ -349,9 +352,7 @@ void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<i
             continue;
         }
         int r1 = r;
-        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap &&
-               rp[r1 + 1] - rp[r1] <= cap - 3)
-            ++r1;
+        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && !is_long(r1)) ++r1;
         desc.push_back(int4{r, n0, r1 - r, rp[r1]});
         r = r1;
     }
@@ -364,6 +365,7 @@ void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<i
 // needs more than lines_max lines, or when the line limit (rather than cap) decides so many
 // cuts that the blocks would run mostly empty: the caller then keeps the gather kernel.
 struct LocalPlan {
+    std::vector<unsigned char> split;  // CSR: rows handed to the split-row kernels (too many x lines)
     std::vector<int4> desc;
     std::vector<int4> hll_ldesc;  // HLL: {first line, lines, slots from the even base, 0}
     std::vector<int2> ldesc;
@@ -378,10 +380,12 @@ bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, 
     const int line_mask = (1 << line_shift) - 1;
     std::vector<int> stamp((size_t)total_lines + 1, -1), rank((size_t)total_lines + 1, 0), cur;
     plan.lcol.assign((size_t)nz + kPad, 0);
+    plan.split.assign((size_t)M, 0);
     plan.desc.clear();
     plan.ldesc.clear();
     plan.lines.clear();
     int widest = 0;
+    long long split_entries = 0;
     int r = 0;
     while (r < M) {
         const int n0 = rp[r];
@@ -409,7 +413,15 @@ bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, 
             }
             ++r1;
         }
-        if (r1 == r) return false;  // one row alone touches more lines than a block may list
+        if (r1 == r) {
+            // one row alone touches more lines than a block may list: it goes to the split-row
+            // (gather) kernels like a long row; a matrix made of such rows keeps the gather kernel
+            plan.split[r] = 1;
+            split_entries += rp[r + 1] - n0;
+            if (split_entries * 20 > nz) return false;
+            ++r;
+            continue;
+        }
         if (cur.empty()) cur.push_back(0);  // only empty rows: the kernel still stages one line
         std::sort(cur.begin(), cur.end());
         for (size_t k = 0; k < cur.size(); ++k) rank[cur[k]] = (int)k;
@@ -500,7 +512,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     // blocks are still (nearly) full, i.e. rows are not tiny
     m->ring_ok = m->stream_cap == kRingCap && Ml > 0 && (double)nz / Ml >= 1.25 * kRingCap / (kRingRows - 1);
     csr_build_blocks(Ml, rp.data(), m->stream_cap, m->ring_ok ? kRingRows - 1 : kStreamRowsCap, desc,
-                     pieces, long_rows);
+                     pieces, long_rows, have_local ? &local.split : nullptr);
     m->num_blocks = (int)desc.size();
     m->num_long = (int)long_rows.size();
     m->num_partial = (int)pieces.size();

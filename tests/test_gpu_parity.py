@@ -502,6 +502,41 @@ def test_x_window_plan_is_refused_for_scattered_columns(gpu, oracle):
         assert_parity(dev.spmv(x, sp.CSR_STREAM), oracle.csr_serial(row_ptr, col, val, x), row_ptr, col, val, x)
 
 
+def test_x_window_plan_keeps_going_past_a_few_scattered_rows(gpu, oracle):
+    """A banded matrix with a handful of rows whose columns are spread over all of x (each
+    needs more lines than a block may list): those rows are handed to the split-row kernels,
+    the rest keeps the x-window plan; fp64 and fp32."""
+    from _util import banded_csr
+    rng = np.random.default_rng(57)
+    M, N = 6000, 40000
+    for dtype in (np.float64, np.float32):
+        row_ptr, col, val = banded_csr(rng, M, N, 30, 200, 0.02, dtype=dtype)
+        lens = np.diff(row_ptr).astype(np.int64)
+        wild = [0, 777, 778, 3000, M - 1]
+        cols, vals = [], []
+        for r in range(M):
+            if r in wild:
+                n = 600 if r != 778 else 300
+                cols.append(np.sort(rng.choice(N, n, replace=False)).astype(np.int32))
+                vals.append(rng.uniform(-1, 1, n).astype(dtype))
+                lens[r] = n
+            else:
+                cols.append(col[row_ptr[r]:row_ptr[r + 1]]); vals.append(val[row_ptr[r]:row_ptr[r + 1]])
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        c2, v2 = np.concatenate(cols).astype(np.int32), np.concatenate(vals).astype(dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        with sp.CsrDevice(M, N, rp, c2, v2) as dev:
+            info = dev.info()
+            assert info["local_blocks"] > 0 and info["long_rows"] == len(wild)
+            for vname, variant in CSR_V:
+                y = dev.spmv(x, variant)
+                if dtype == np.float64:
+                    assert_parity(y, oracle.csr_serial(rp, c2, v2, x), rp, c2, v2, x, what=f"scattered rows {vname}")
+                else:
+                    ref = oracle.csr_f32_accum64(rp, c2, v2, x)
+                    assert np.max(np.abs(y.astype(np.float64) - ref)) / np.max(np.abs(ref)) <= FP32_NORMWISE_RTOL
+
+
 def test_x_window_kernel_with_long_rows_row_blocks_and_foreign_x(gpu, oracle):
     """Long rows go to the split-row kernels beside the x-window blocks; a row block keeps
     global columns; run_on with a 128-byte aligned x uses the x-window kernel, a misaligned x
