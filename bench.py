@@ -332,7 +332,7 @@ def main():
     dev.set_x(x)
 
     # the exchange step (N > 1): RCCL all-gatherv of y
-    comm, exchange = None, "none"
+    comm, exchange, gather_mode = None, "none", 0
     if world > 1:
         exchange = args.exchange
         if exchange == "rccl":
@@ -344,6 +344,10 @@ def main():
                     return box[0]
                 comm = NativeComm(rank, world, share)
                 dev.step_time(bounds, variant, 0, 1)      # first exchange: fail here, not in the timed region
+                # which all-gatherv is faster on THIS node (grouped broadcasts vs padded all-gather)
+                gather_mode, ms_b, ms_g = comm.autotune(dev.y_ptr, bounds, vb, 10)
+                log(f"[rank {rank}] all-gatherv: grouped broadcasts {ms_b * 1e3:.1f} us, padded all-gather "
+                    f"{'rejected' if ms_g < 0 else f'{ms_g * 1e3:.1f} us'} -> mode {gather_mode}")
             except Exception as exc:  # both transports are RCCL; fall back to torch's
                 log(f"[rank {rank}] native RCCL communicator unavailable ({exc})")
                 ok = 0
@@ -478,7 +482,9 @@ def main():
             "config": {"workload": wl["name"] + (" HLL hack=32" if hll_mode else " CSR"),
                        "rows": M, "cols": N, "nnz": nnz_total, "x": "ones",
                        "kernel": kernel_name, "parallelism": f"row-block x{world}" if world > 1 else "1 GPU",
-                       "exchange": {"none": "none", "rccl": "RCCL all-gatherv(y), C-ABI communicator",
+                       "exchange": {"none": "none", "rccl": "RCCL all-gatherv(y), C-ABI communicator, " +
+                                    ("one padded ncclAllGather + scatter" if gather_mode == 1 else
+                                     "one ncclBroadcast per owner in a group") + " (picked by timing both)",
                                     "torch": "RCCL all-gatherv(y) via torch.distributed",
                                     "gloo-host": "DEBUG: all-gatherv(y) through host memory (gloo)"}[exchange],
                        "nnz_imbalance_max_over_mean": round(float(per_rank[:, 4].max() / per_rank[:, 4].mean()), 4),

@@ -195,6 +195,18 @@ int spmv_hip_comm_destroy(void);
  * grouped set of ncclBroadcast calls on `stream` (NULL = library stream).
  * value_bytes is 8 (fp64) or 4 (fp32). */
 int spmv_hip_comm_allgatherv(void *d_y, const int *bounds, int value_bytes, void *stream);
+/* The scatter half of the padded all-gather on its own: slice p of `d_stage` (at p * widest slice
+ * values) -> rows [bounds[p], bounds[p+1]) of d_y, for every p but skip_rank (-1: all). */
+int spmv_hip_comm_scatter_staged(const void *d_stage, void *d_y, const int *bounds, int ranks, int skip_rank,
+                                 int value_bytes, void *stream);
+/* Collective.  Times the two implementations of the all-gatherv on this node -- (0) one
+ * ncclBroadcast per owner inside a group, in place; (1) a single ncclAllGather of slices padded to the
+ * widest one into a staging buffer + one scatter kernel -- takes the maximum over ranks, checks that (1)
+ * reproduces (0) bit for bit, and makes the faster one the mode spmv_hip_comm_allgatherv uses from
+ * then on (also settable: spmv_hip_set_tuning("gather_mode", 0 | 1)).  d_y must already hold a
+ * gathered vector.  ms_modes[2] (optional) receives the two times, ms_modes[1] < 0 if (1) was rejected. */
+int spmv_hip_comm_autotune(void *d_y, const int *bounds, int value_bytes, int iters, int *mode_out,
+                           float *ms_modes);
 /* One multi-GPU step, timed: SpMV on this rank's rows then the all-gatherv of
  * the library-owned y, both on the library stream, events around each part.
  * ms_kernel / ms_exchange receive `iters` values (either may be NULL). */

@@ -179,6 +179,9 @@ _PROTOTYPES = {
     "spmv_hip_hll_run_on": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmv_hip_hll_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p]),
     "spmv_hip_partition_rows": (C.c_int, [C.c_int, c_int_p, C.c_int, c_int_p]),
+    "spmv_hip_comm_scatter_staged": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p]),
+    "spmv_hip_comm_autotune": (C.c_int, [C.c_void_p, c_int_p, C.c_int, C.c_int, c_int_p, c_float_p]),
     "spmv_hip_partition_hacks": (C.c_int, [C.POINTER(HLLMatrix), C.c_int, c_int_p]),
     "spmv_hip_hll_upload_part": (C.c_int, [C.POINTER(HLLMatrix), C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p)]),

@@ -91,6 +91,16 @@ class NativeComm:
                                                   int(value_bytes), C.c_void_p(stream)),
                "spmv_hip_comm_allgatherv")
 
+    def autotune(self, d_y: int, bounds, value_bytes=8, iters=10):
+        """Collective: time both all-gatherv implementations on this node, keep the faster one that
+        reproduces the other bit for bit.  Returns (mode, ms_broadcasts, ms_padded_allgather)."""
+        b = np.ascontiguousarray(bounds, dtype=np.int32)
+        mode = C.c_int(0)
+        ms = (C.c_float * 2)()
+        _check(nat.lib().spmv_hip_comm_autotune(C.c_void_p(d_y), b.ctypes.data_as(nat.c_int_p), int(value_bytes),
+                                                int(iters), C.byref(mode), ms), "spmv_hip_comm_autotune")
+        return int(mode.value), float(ms[0]), float(ms[1])
+
     def close(self):
         nat.lib().spmv_hip_comm_destroy()
 

@@ -272,7 +272,51 @@ def test_single_rank_communicator(gpu):
         y = dev.spmv(x)
         comm.allgatherv(dev.y_ptr, np.array([0, 500], np.int32), 8)
         assert np.array_equal(dev.get_y(), y)
+        # both implementations of the all-gatherv, timed and compared on this "node" of one rank
+        from sparsematrixvectormultiplication_amd.device import set_tuning
+        mode, ms_b, ms_g = comm.autotune(dev.y_ptr, np.array([0, 500], np.int32), 8, 3)
+        assert mode in (0, 1) and ms_b > 0 and ms_g > 0       # ms_g < 0 would mean: results differed
+        assert np.array_equal(dev.get_y(), y)
+        for forced in (1, 0):
+            set_tuning("gather_mode", forced)
+            comm.allgatherv(dev.y_ptr, np.array([0, 500], np.int32), 8)
+            assert np.array_equal(dev.get_y(), y)
     comm.close()
+
+
+@pytest.mark.parametrize("vb", [8, 4])
+def test_padded_allgather_scatter_places_every_slice(gpu, vb):
+    """The scatter kernel behind all-gatherv mode 1, without a communicator: a staging buffer laid
+    out as RCCL's all-gather leaves it (slice p at p * widest) goes to the right rows of y for
+    unequal, empty and single-row slices; the skipped rank's rows stay as they were."""
+    import ctypes as C
+    L = sp.lib()
+    dt = np.float64 if vb == 8 else np.float32
+    bounds = np.array([0, 700, 700, 701, 1500, 4096, 4100], np.int32)   # 6 "ranks"
+    ranks, M = len(bounds) - 1, int(bounds[-1])
+    widest = int(np.max(np.diff(bounds)))
+    rng = np.random.default_rng(vb)
+    stage = rng.uniform(-1, 1, ranks * widest).astype(dt)
+    y0 = rng.uniform(-1, 1, M).astype(dt)
+    d_stage, d_y = C.c_void_p(), C.c_void_p()
+    assert L.spmv_hip_malloc(C.byref(d_stage), stage.nbytes) == 0 and L.spmv_hip_malloc(C.byref(d_y), y0.nbytes) == 0
+    try:
+        for skip in (-1, 0, 3, 5):
+            assert L.spmv_hip_memcpy_h2d(d_stage, stage.ctypes.data_as(C.c_void_p), stage.nbytes) == 0
+            assert L.spmv_hip_memcpy_h2d(d_y, y0.ctypes.data_as(C.c_void_p), y0.nbytes) == 0
+            assert L.spmv_hip_comm_scatter_staged(d_stage, d_y, bounds.ctypes.data_as(sp._native.c_int_p), ranks,
+                                                  skip, vb, None) == 0
+            sp.hip_sync()
+            y = np.empty(M, dt)
+            assert L.spmv_hip_memcpy_d2h(y.ctypes.data_as(C.c_void_p), d_y, y.nbytes) == 0
+            want = y0.copy()
+            for p in range(ranks):
+                if p != skip:
+                    want[bounds[p]:bounds[p + 1]] = stage[p * widest:p * widest + bounds[p + 1] - bounds[p]]
+            assert y.tobytes() == want.tobytes(), f"skip={skip}"
+    finally:
+        L.spmv_hip_free(d_stage)
+        L.spmv_hip_free(d_y)
 
 
 # ------------------------------------------ full-size, size-independent
