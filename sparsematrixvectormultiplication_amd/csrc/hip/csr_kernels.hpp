@@ -973,16 +973,5 @@ __global__ __launch_bounds__(64) void csr_long_finish(int count, const int4 *__r
     if (threadIdx.x == 0) y[d.x] = acc;
 }
 
-// Touch `n` 16-byte words so that L2 and the Infinity Cache are refilled with
-// scratch data (answers clear_cache_kernel, cuda_src/utility.cu:140-145).
-__global__ __launch_bounds__(kBlock) void flush_kernel(uint4 *__restrict__ buf, size_t n) {
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (; i < n; i += stride) {
-        uint4 w = buf[i];
-        w.x += 1u;
-        buf[i] = w;
-    }
-}
 
 }  // namespace spmv

@@ -323,15 +323,6 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
 // flat slab is two trivial kernels: the per-hack maximum row length, then a fill that
 // copies each row and pads it exactly as the host builder does (value 0, column = the
 // row's last real column, 0 for an empty row; src/hll_matrix.c:129-140,241-246).
-__global__ __launch_bounds__(kBlock) void hll_hack_maxnz(int M, int hacks, const int *__restrict__ row_ptr,
-                                                         int *__restrict__ maxnz) {
-    const int h = blockIdx.x * kBlock + threadIdx.x;
-    if (h >= hacks) return;
-    const int r0 = h * kHack, r1 = min(r0 + kHack, M);
-    int m = 0;
-    for (int r = r0; r < r1; ++r) m = max(m, row_ptr[r + 1] - row_ptr[r]);
-    maxnz[h] = m;
-}
 
 // one wavefront per row: lanes stride over the row's maxnz slots
 template <typename T>

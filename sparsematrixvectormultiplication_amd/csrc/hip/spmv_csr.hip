@@ -1,0 +1,516 @@
+// spmv_csr.hip -- CSR side of the C-ABI: upload-time preprocessing (workgroup blocks, the
+// x-window plan, split long rows), kernel launchers, timing.  Replaces the device code of the
+// reference's per-matrix CSR section (/root/reference/main_cuda.cu:135-145, :149-166, :212-238,
+// :285-317, :682-685).
+#include "spmv_internal.hpp"
+
+// ----------------------------------------------------------- CSR: upload
+namespace {
+
+// Cut rows [0, M) (row_ptr rebased to 0) into workgroup-sized blocks for the
+// stream kernels: desc = {first row, first entry, rows, end entry}, each block's entries
+// (counted from the even entry at or below its first) fit `cap`.  A row that
+// cannot be staged is cut into pieces {row, first entry, end entry, slot} whose
+// partial sums csr_long_finish adds up per long row {row, first slot, pieces, 0}.
+// `split` (optional, one byte per row) marks rows that go to the split-row kernels whatever their
+// length: rows the x-window plan cannot take (more x lines than a block may list).
+void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<int4> &desc,
+                      std::vector<int4> &pieces, std::vector<int4> &long_rows,
+                      const std::vector<unsigned char> *split = nullptr) {
+    desc.clear();
+    pieces.clear();
+    long_rows.clear();
+    auto is_long = [&](int row) { return rp[row + 1] - rp[row] > cap - 3 || (split && (*split)[row]); };
+    int r = 0;
+    while (r < M) {
+        const int n0 = rp[r];
+        const int base = n0 & kBaseMask;
+        if (is_long(r)) {
+            const int first_slot = (int)pieces.size();
+            for (int p = n0; p < rp[r + 1]; p += kLongPiece)
+                pieces.push_back(int4{r, p, std::min(p + kLongPiece, rp[r + 1]), (int)pieces.size()});
+            long_rows.push_back(int4{r, first_slot, (int)pieces.size() - first_slot, 0});
+            ++r;
+            continue;
+        }
+        int r1 = r;
+        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && !is_long(r1)) ++r1;
+        desc.push_back(int4{r, n0, r1 - r, rp[r1]});
+        r = r1;
+    }
+}
+
+
+bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, int cap, int rows_cap,
+                     int line_shift, int lines_max, const std::vector<int4> &baseline, LocalPlan &plan) {
+    const int total_lines = (int)(((long long)N + (1 << line_shift) - 1) >> line_shift);
+    const int line_mask = (1 << line_shift) - 1;
+    std::vector<int> stamp((size_t)total_lines + 1, -1), rank((size_t)total_lines + 1, 0), cur;
+    plan.lcol.assign((size_t)nz + kPad, 0);
+    plan.split.assign((size_t)M, 0);
+    plan.desc.clear();
+    plan.ldesc.clear();
+    plan.lines.clear();
+    int widest = 0;
+    long long split_entries = 0;
+    int r = 0;
+    while (r < M) {
+        const int n0 = rp[r];
+        const int base = n0 & kBaseMask;
+        if (rp[r + 1] - n0 > cap - 3) {  // long row: csr_long_pieces, as in csr_build_blocks
+            ++r;
+            continue;
+        }
+        const int blk = (int)plan.desc.size();
+        cur.clear();
+        int r1 = r;
+        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && rp[r1 + 1] - rp[r1] <= cap - 3) {
+            const size_t before = cur.size();
+            for (int e = rp[r1]; e < rp[r1 + 1]; ++e) {
+                const int l = col[e] >> line_shift;
+                if (stamp[l] != blk) {
+                    stamp[l] = blk;
+                    cur.push_back(l);
+                }
+            }
+            if ((int)cur.size() > lines_max) {  // this row does not fit any more: take it back
+                for (size_t k = before; k < cur.size(); ++k) stamp[cur[k]] = -1;
+                cur.resize(before);
+                break;
+            }
+            ++r1;
+        }
+        if (r1 == r) {
+            // one row alone touches more lines than a block may list: it goes to the split-row
+            // (gather) kernels like a long row; a matrix made of such rows keeps the gather kernel
+            plan.split[r] = 1;
+            split_entries += rp[r + 1] - n0;
+            if (split_entries * 20 > nz) return false;
+            ++r;
+            continue;
+        }
+        if (cur.empty()) cur.push_back(0);  // only empty rows: the kernel still stages one line
+        std::sort(cur.begin(), cur.end());
+        for (size_t k = 0; k < cur.size(); ++k) rank[cur[k]] = (int)k;
+        for (int e = rp[r]; e < rp[r1]; ++e)
+            plan.lcol[e] = (unsigned short)((rank[col[e] >> line_shift] << line_shift) | (col[e] & line_mask));
+        plan.desc.push_back(int4{r, n0, r1 - r, rp[r1]});
+        plan.ldesc.push_back(int2{(int)plan.lines.size(), (int)cur.size()});
+        plan.lines.insert(plan.lines.end(), cur.begin(), cur.end());
+        widest = std::max(widest, (int)cur.size());
+        r = r1;
+        // the line limit is cutting blocks well short of what cap alone allows: give up early
+        if ((plan.desc.size() & 1023) == 0) {
+            const size_t plain = std::lower_bound(baseline.begin(), baseline.end(), r,
+                                                  [](const int4 &d, int row) { return d.x < row; }) -
+                                 baseline.begin();
+            if (plan.desc.size() > plain + plain / 5 + 16) return false;
+        }
+    }
+    if (plan.desc.size() > baseline.size() + baseline.size() / 5 + 1) return false;
+    // the kernel stages whole passes of kLocalLineQuantum lines and reads the list unconditionally
+    plan.stage_lines = std::max(kLocalLineQuantum,
+                                (widest + kLocalLineQuantum - 1) / kLocalLineQuantum * kLocalLineQuantum);
+    plan.lines.insert(plan.lines.end(), (size_t)kLocalLinesMax, 0);
+    return true;
+}
+
+template <typename T>
+int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const T *values, int row0,
+                    int row1, spmv_csr_dev **out) {
+    if (need_device()) return -1;
+    if (!out) return fail("csr_upload: out is NULL");
+    *out = nullptr;
+    if (M < 0 || N < 0 || !row_ptr) return fail("csr_upload: bad arguments");
+    if (row0 < 0 || row1 < row0 || row1 > M) return fail("csr_upload: bad row range [%d, %d) of %d", row0, row1, M);
+    const int Ml = row1 - row0;
+    const int e0 = row_ptr[row0], e1 = row_ptr[row1];
+    const long long nz = (long long)e1 - e0;
+    if (nz < 0) return fail("csr_upload: row_ptr is not monotone");
+    if (nz > 0 && (!col_idx || !values)) return fail("csr_upload: col_idx / values are NULL");
+    if ((unsigned long long)N * sizeof(T) >= (1ull << 32))
+        return fail("csr_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
+    // a column index outside [0, N) would make the kernels gather out of bounds
+    for (int e = e0; e < e1; ++e)
+        if ((unsigned)col_idx[e] >= (unsigned)N)
+            return fail("csr_upload: column index %d at entry %d is outside [0, %d)", col_idx[e], e, N);
+
+    spmv_csr_dev *m = new (std::nothrow) spmv_csr_dev();
+    if (!m) return fail("csr_upload: out of host memory");
+    m->value_bytes = (int)sizeof(T);
+    m->M_local = Ml;
+    m->M_total = M;
+    m->N = N;
+    m->row0 = row0;
+    m->nz = nz;
+
+    std::vector<int> rp((size_t)Ml + 1);
+    int max_row = 0;
+    for (int r = 0; r <= Ml; ++r) rp[r] = row_ptr[row0 + r] - e0;
+    for (int r = 0; r < Ml; ++r) {
+        if (rp[r + 1] < rp[r]) {
+            delete m;
+            return fail("csr_upload: row_ptr decreases at row %d", row0 + r);
+        }
+        max_row = std::max(max_row, rp[r + 1] - rp[r]);
+    }
+    m->max_row = max_row;
+
+    std::vector<int4> desc, pieces, long_rows;
+    // The x-window kernel first (csr_stream_local): own blocks at a 2048-entry stage.  One stage
+    // size per handle, so that its blocks, the gather kernel's and the split long rows agree on
+    // which rows are long: a matrix that gets a plan runs everything at 2048.  An explicit
+    // stream_cap other than 2048 asks for the gather kernel's configuration and skips the plan.
+    LocalPlan local;
+    bool have_local = false;
+    constexpr int line_shift = sizeof(T) == 8 ? 4 : 5;  // 128-byte lines
+    // (1024-entry blocks were tried for small matrices: cant-like 13.2 us against 11.7 us at 2048)
+    const int lcap = g_local_cap ? g_local_cap : 2048;
+    if (g_stream_local && nz > 0 && (g_stream_cap == 0 || g_stream_cap == lcap)) {
+        csr_build_blocks(Ml, rp.data(), lcap, kStreamRowsCap, desc, pieces, long_rows);
+        have_local = csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, lcap, kStreamRowsCap, line_shift,
+                                     kLocalLinesMax, desc, local);
+    }
+    // else: larger stages amortise per-workgroup latency on big matrices; small ones need
+    // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
+    m->stream_cap = have_local ? lcap : (g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048));
+    m->local_cap = lcap;
+    // the ring kernel stages at most kRingRows - 1 rows per block; only worth it when such
+    // blocks are still (nearly) full, i.e. rows are not tiny
+    m->ring_ok = m->stream_cap == kRingCap && Ml > 0 && (double)nz / Ml >= 1.25 * kRingCap / (kRingRows - 1);
+    csr_build_blocks(Ml, rp.data(), m->stream_cap, m->ring_ok ? kRingRows - 1 : kStreamRowsCap, desc,
+                     pieces, long_rows, have_local ? &local.split : nullptr);
+    m->num_blocks = (int)desc.size();
+    m->num_long = (int)long_rows.size();
+    m->num_partial = (int)pieces.size();
+    const int num_partial = m->num_partial;
+
+    int rc = 0;
+    rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), (size_t)kRingRows + 64);
+    if (!rc && have_local) {
+        rc |= upload_array(&m->ldesc4, local.desc.data(), local.desc.size(), 1);
+        if (!rc) rc |= upload_array(&m->ldesc, local.ldesc.data(), local.ldesc.size(), 1);
+        if (!rc) rc |= upload_array(&m->lines, local.lines.data(), local.lines.size(), 0);
+        if (!rc) rc |= upload_array(&m->lcol, local.lcol.data(), local.lcol.size(), 0);
+        if (!rc) {
+            m->local_blocks = (int)local.desc.size();
+            m->local_stage_lines = local.stage_lines;
+            m->local_lines = (long long)local.lines.size() - kLocalLinesMax;
+        }
+    }
+    if (!rc) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
+    if (!rc) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
+    if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
+    if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
+    if (!rc && num_partial) rc |= upload_array(&m->pieces, pieces.data(), pieces.size(), 0);
+    if (!rc && num_partial) {
+        hipError_t e = hipMalloc(&m->partial, (size_t)num_partial * sizeof(T));
+        if (e != hipSuccess) rc = fail("hipMalloc(partial) failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        // x is read in whole 128-byte lines by csr_stream_local: room for the tail of the last one
+        const size_t x_bytes = std::max<size_t>((size_t)N, 1) * sizeof(T) + kLineBytes;
+        hipError_t e = hipMalloc(&m->x, x_bytes);
+        if (e == hipSuccess) e = hipMalloc(&m->y, std::max<size_t>((size_t)M, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMemset(m->x, 0, x_bytes);
+        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)M, 1) * sizeof(T));
+        if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        spmv_hip_csr_free(m);
+        return -1;
+    }
+    m->device_bytes = rp.size() * 4 + ((size_t)nz + kPad) * (4 + sizeof(T)) + desc.size() * 16 +
+                      long_rows.size() * 16 + pieces.size() * 16 + (size_t)num_partial * sizeof(T) +
+                      ((size_t)N + (size_t)M) * sizeof(T);
+    if (have_local)
+        m->device_bytes += local.desc.size() * 24 + local.lines.size() * 4 + local.lcol.size() * 2;
+
+    // lanes per row for the SUBWAVE kernel: about half the mean row length,
+    // rounded to a power of two, so that a typical row takes 1-2 passes
+    const double mean = Ml ? (double)nz / Ml : 0.0;
+    int lanes = pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)));
+    m->lanes_per_row = std::min(32, std::max(2, lanes));
+    m->auto_variant = SPMV_CSR_STREAM;
+    *out = m;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
+                                   const double *values, int row0, int row1, spmv_csr_dev **out) {
+    return csr_upload_impl<double>(M, N, row_ptr, col_idx, values, row0, row1, out);
+}
+
+extern "C" int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx,
+                                       const float *values, int row0, int row1, spmv_csr_dev **out) {
+    return csr_upload_impl<float>(M, N, row_ptr, col_idx, values, row0, row1, out);
+}
+
+extern "C" int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **out) {
+    if (!csr) return fail("csr_upload_matrix: csr is NULL");
+    return spmv_hip_csr_upload(csr->M, csr->N, csr->row_ptr, csr->col_idx, csr->values, 0, csr->M, out);
+}
+
+extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
+    if (!m) return;
+    (void)hipFree(m->row_ptr);
+    (void)hipFree(m->col);
+    (void)hipFree(m->val);
+    (void)hipFree(m->desc);
+    (void)hipFree(m->ldesc4);
+    (void)hipFree(m->ldesc);
+    (void)hipFree(m->lines);
+    (void)hipFree(m->lcol);
+    (void)hipFree(m->long_rows);
+    (void)hipFree(m->pieces);
+    (void)hipFree(m->partial);
+    (void)hipFree(m->x);
+    (void)hipFree(m->y);
+    delete m;
+}
+
+extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
+    if (!m || !out) return fail("csr_info: NULL argument");
+    memset(out, 0, sizeof *out);
+    out->M_local = m->M_local;
+    out->M_total = m->M_total;
+    out->N = m->N;
+    out->row0 = m->row0;
+    out->nz = m->nz;
+    out->value_bytes = m->value_bytes;
+    out->auto_variant = m->auto_variant;
+    out->lanes_per_row = m->lanes_per_row;
+    out->stream_blocks = m->num_blocks;
+    out->long_rows = m->num_long;
+    const long long vb = m->value_bytes;
+    // nnz (val + 4) + 4 (M + 1) + val M [y] + val N [x]
+    out->algo_bytes = m->nz * (vb + 4) + 4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
+    out->device_bytes = (long long)m->device_bytes;
+    out->local_blocks = m->local_blocks;
+    out->local_stage_lines = m->local_stage_lines;
+    out->local_lines = m->local_lines;
+    if (m->local_blocks > 0)
+        out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
+                            4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_set_x(spmv_csr_dev *m, const void *x_host) {
+    if (need_device()) return -1;
+    if (!m || !x_host) return fail("csr_set_x: NULL argument");
+    HIP_TRY(hipMemcpyAsync(m->x, x_host, (size_t)m->N * m->value_bytes, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_get_y(spmv_csr_dev *m, void *y_host) {
+    if (need_device()) return -1;
+    if (!m || !y_host) return fail("csr_get_y: NULL argument");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(y_host, m->y, (size_t)m->M_total * m->value_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" void *spmv_hip_csr_x_ptr(spmv_csr_dev *m) { return m ? m->x : nullptr; }
+extern "C" void *spmv_hip_csr_y_ptr(spmv_csr_dev *m) { return m ? m->y : nullptr; }
+
+// ----------------------------------------------------------- CSR: launch
+namespace {
+
+template <typename T, int L>
+void launch_vector(const spmv_csr_dev *m, const T *x, T *y, hipStream_t s) {
+    constexpr int rows = kBlock / L;
+    const int grid = (m->M_local + rows - 1) / rows;
+    hipLaunchKernelGGL((csr_vector<T, L, 1, false>), dim3(grid), dim3(kBlock), 0, s, m->M_local,
+                       m->row_ptr, m->col, (const T *)m->val, x, y);
+}
+
+template <typename T>
+int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStream_t s) {
+    if (m->M_local == 0) return 0;
+    T *y = y_full + m->row0;
+    if (variant == SPMV_CSR_AUTO) variant = m->auto_variant;
+    switch (variant) {
+        case SPMV_CSR_THREAD_ROW: {
+            const int grid = (m->M_local + kBlock - 1) / kBlock;
+            hipLaunchKernelGGL((csr_thread_row<T>), dim3(grid), dim3(kBlock), 0, s, m->M_local,
+                               m->row_ptr, m->col, (const T *)m->val, x, y);
+            break;
+        }
+        case SPMV_CSR_WAVE_ROW: {
+            constexpr int rows = kBlock / 64;
+            const int grid = (m->M_local + rows - 1) / rows;
+            hipLaunchKernelGGL((csr_vector<T, 64, 2, true>), dim3(grid), dim3(kBlock), 0, s,
+                               m->M_local, m->row_ptr, m->col, (const T *)m->val, x, y);
+            break;
+        }
+        case SPMV_CSR_SUBWAVE:
+            switch (m->lanes_per_row) {
+                case 2: launch_vector<T, 2>(m, x, y, s); break;
+                case 4: launch_vector<T, 4>(m, x, y, s); break;
+                case 8: launch_vector<T, 8>(m, x, y, s); break;
+                case 16: launch_vector<T, 16>(m, x, y, s); break;
+                default: launch_vector<T, 32>(m, x, y, s); break;
+            }
+            break;
+        case SPMV_CSR_STREAM: {
+            if (m->num_blocks > 0) {
+                const int per_xcd = (m->num_blocks + 7) / 8;
+#define SPMV_ARGS m->desc, m->row_ptr, m->col, (const T *)m->val, x, y
+#define SPMV_LAUNCH_PROD(NT, CAP, BLOCK)                                                          \
+    hipLaunchKernelGGL((csr_stream<T, NT, CAP, BLOCK>), dim3(grid_blocks), dim3(BLOCK), 0, s,      \
+                       m->num_blocks, chunk, SPMV_ARGS)
+#define SPMV_LAUNCH_FLAGS(MACRO, ...)              \
+    do {                                           \
+        if (g_stream_nt) MACRO(true, __VA_ARGS__); \
+        else MACRO(false, __VA_ARGS__);            \
+    } while (0)
+                // blocks per XCD run; a dummy empty block is harmless for the persistent kernels
+                const int chunk = g_stream_xcd < 0 ? per_xcd : g_stream_xcd;
+                const int grid_blocks = chunk > 0 ? (m->num_blocks + 8 * chunk - 1) / (8 * chunk) * (8 * chunk)
+                                                  : m->num_blocks;
+                const int cap = m->stream_cap, blk = g_stream_block;
+                // the x-window kernel reads whole aligned lines of x
+                const bool local = (g_stream_kind == -1 || g_stream_kind == 5) && m->local_blocks > 0 &&
+                                   ((uintptr_t)x & (kLineBytes - 1)) == 0;
+                if (local) {
+                    // runs of 16 neighbouring blocks per XCD: each L2 keeps its own window of x lines
+                    // (measured flat from 8 to 128 on three matrices); stream_xcd overrides
+                    const int lchunk = g_stream_xcd < 0 ? (m->local_blocks + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
+                    const int lgrid = lchunk > 0 ? (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk)
+                                                 : m->local_blocks;
+                    const size_t lds = std::max((size_t)m->local_cap * sizeof(T), (size_t)m->local_stage_lines * kLineBytes);
+#define SPMV_LOCAL(NT, CAP)                                                                                   \
+    hipLaunchKernelGGL((csr_stream_local<T, NT, CAP>), dim3(lgrid), dim3(kBlock), lds, s, m->local_blocks, lchunk, \
+                       m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const T *)m->val, x, y)
+                    // streamed-once hint only when the matrix cannot live in the 256 MiB Infinity Cache anyway
+                    // (cant-like, 53 MB: 10.9 us without it, 11.7 us with; fem-large: 160 vs 151 us)
+                    const bool lnt = g_local_nt < 0 ? m->nz * (long long)(sizeof(T) + 2) > (128LL << 20) : g_local_nt != 0;
+                    if (m->local_cap == 1024) { if (lnt) SPMV_LOCAL(true, 1024); else SPMV_LOCAL(false, 1024); }
+                    else { if (lnt) SPMV_LOCAL(true, 2048); else SPMV_LOCAL(false, 2048); }
+#undef SPMV_LOCAL
+                } else if (g_stream_kind == 4 && m->ring_ok) {
+                    // loader / consumer ring: one persistent 512-thread workgroup per CU
+                    const int wgs = std::max(1, std::min(g_num_cus * g_pipe_wgs_per_cu, m->num_blocks));
+                    if (g_pipe_wgs_per_cu >= 2) {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_ring<T, true, 3, 2>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_ring<T, false, 3, 2>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                    } else {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_ring<T, true, 4, 3>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_ring<T, false, 4, 3>), dim3(wgs), dim3(kRingBlock), 0, s, m->num_blocks, SPMV_ARGS);
+                    }
+                } else if (g_stream_kind >= 10 && g_stream_kind <= 17 && (cap == 2048 || cap == 4096)) {
+                    // ablation probes (measurement only; y is not A x)
+#define SPMV_PROBE(CAP, MODE) hipLaunchKernelGGL((csr_probe<T, true, CAP, MODE>), dim3(grid_blocks), dim3(kBlock), 0, s, m->num_blocks, chunk, g_probe_mask, SPMV_ARGS)
+                    const int mode = g_stream_kind - 10;
+                    if (cap == 2048) { if (mode == 0) SPMV_PROBE(2048, 0); else if (mode == 1) SPMV_PROBE(2048, 1); else if (mode == 2) SPMV_PROBE(2048, 2); else if (mode == 3) SPMV_PROBE(2048, 3); else if (mode == 5) SPMV_PROBE(2048, 5); else SPMV_PROBE(2048, 7); }
+                    else { if (mode == 0) SPMV_PROBE(4096, 0); else if (mode == 1) SPMV_PROBE(4096, 1); else if (mode == 2) SPMV_PROBE(4096, 2); else if (mode == 3) SPMV_PROBE(4096, 3); else if (mode == 5) SPMV_PROBE(4096, 5); else SPMV_PROBE(4096, 7); }
+#undef SPMV_PROBE
+                } else if (g_stream_kind == 2 && cap <= 4096) {
+                    // persistent grid: what is resident at once (at least two blocks each)
+                    int wgs = std::max(8, std::min(g_num_cus * g_pipe_wgs_per_cu, (m->num_blocks + 1) / 2) / 8 * 8);
+                    if (cap == 2048) {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 2048>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                    } else {
+                        if (g_stream_nt) hipLaunchKernelGGL((csr_stream_pipe<T, true, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                        else hipLaunchKernelGGL((csr_stream_pipe<T, false, 4096>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                    }
+                } else if ((g_stream_kind == 1 || g_stream_kind == 3) && cap <= 4096) {
+                    // kind 1: one block per workgroup; kind 3: persistent grid-stride
+                    const bool persist = g_stream_kind == 3;
+                    const int wgs = persist ? std::max(8, std::min(g_num_cus * g_pipe_wgs_per_cu, m->num_blocks) / 8 * 8)
+                                            : grid_blocks;
+#define SPMV_WALK(NT, CAP, P) hipLaunchKernelGGL((csr_stream_walk<T, NT, CAP, P>), dim3(wgs), dim3(kBlock), 0, s, m->num_blocks, chunk, SPMV_ARGS)
+                    if (cap == 2048) {
+                        if (persist) { if (g_stream_nt) SPMV_WALK(true, 2048, true); else SPMV_WALK(false, 2048, true); }
+                        else { if (g_stream_nt) SPMV_WALK(true, 2048, false); else SPMV_WALK(false, 2048, false); }
+                    } else {
+                        if (persist) { if (g_stream_nt) SPMV_WALK(true, 4096, true); else SPMV_WALK(false, 4096, true); }
+                        else { if (g_stream_nt) SPMV_WALK(true, 4096, false); else SPMV_WALK(false, 4096, false); }
+                    }
+#undef SPMV_WALK
+                } else if (cap == 1024) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 1024, 256);
+                } else if (cap == 2048) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 2048, 256);
+                } else if (cap == 4096 && blk == 512) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 4096, 512);
+                } else if (cap == 4096) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 4096, 256);
+                } else if (blk == 1024) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 8192, 1024);
+                } else {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 8192, 512);
+                }
+#undef SPMV_LAUNCH_FLAGS
+#undef SPMV_LAUNCH_PROD
+#undef SPMV_ARGS
+            }
+            if (m->num_long) {
+                hipLaunchKernelGGL((csr_long_pieces<T, true>), dim3(m->num_partial), dim3(kBlock), 0, s,
+                                   m->num_partial, m->pieces, m->col, (const T *)m->val, x,
+                                   (T *)m->partial);
+                hipLaunchKernelGGL((csr_long_finish<T>), dim3(m->num_long), dim3(64), 0, s,
+                                   m->num_long, m->long_rows, (const T *)m->partial, y);
+            }
+            break;
+        }
+        default:
+            return fail("unknown CSR variant %d", variant);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s) {
+    if (m->value_bytes == 8) return csr_launch<double>(m, variant, (const double *)x, (double *)y, s);
+    return csr_launch<float>(m, variant, (const float *)x, (float *)y, s);
+}
+
+
+
+extern "C" int spmv_hip_csr_run(spmv_csr_dev *m, int variant) {
+    if (need_device()) return -1;
+    if (!m) return fail("csr_run: NULL handle");
+    return csr_launch_any(m, variant, m->x, m->y, g_stream);
+}
+
+extern "C" int spmv_hip_csr_run_on(spmv_csr_dev *m, int variant, const void *d_x, void *d_y, void *stream) {
+    if (need_device()) return -1;
+    if (!m || !d_x || !d_y) return fail("csr_run_on: NULL argument");
+    return csr_launch_any(m, variant, d_x, d_y, stream ? (hipStream_t)stream : g_stream);
+}
+
+namespace {
+
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, int zero_y,
+                                 float *ms_each) {
+    if (need_device()) return -1;
+    if (!m) return fail("csr_time: NULL handle");
+    return time_loop(
+        warmup, iters, ms_each, [&] { return csr_launch_any(m, variant, m->x, m->y, g_stream); },
+        [&]() -> int {
+            if (zero_y) HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M_total * m->value_bytes, g_stream));
+            return 0;
+        });
+}
+
+namespace {
+
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_time_graph(spmv_csr_dev *m, int variant, int iters, int replays, float *ms_per_iter) {
+    if (need_device()) return -1;
+    if (!m) return fail("csr_time_graph: NULL handle");
+    return graph_loop(iters, replays, ms_per_iter, [&] { return csr_launch_any(m, variant, m->x, m->y, g_stream); });
+}
+

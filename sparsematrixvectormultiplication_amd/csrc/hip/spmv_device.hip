@@ -1,0 +1,224 @@
+// spmv_device.hip -- library state, device bring-up, tuning knobs and the raw memory helpers of
+// include/spmv_hip.h.  Stands where the reference's CUDA driver selects and queries the device
+// (/root/reference/main_cuda.cu:100-133) and flushes caches between tests (cuda_src/utility.cu:148-175).
+// Nothing here computes on the host: if HIP is unusable every entry point returns -1 with a message.
+#include "spmv_internal.hpp"
+
+namespace {
+
+// Touch `n` 16-byte words so that L2 and the Infinity Cache are refilled with
+// scratch data (answers clear_cache_kernel, cuda_src/utility.cu:140-145).
+__global__ __launch_bounds__(kBlock) void flush_kernel(uint4 *__restrict__ buf, size_t n) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (; i < n; i += stride) {
+        uint4 w = buf[i];
+        w.x += 1u;
+        buf[i] = w;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ state
+static thread_local char g_error[512] = "";
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+static void *g_flush_buf = nullptr;
+static size_t g_flush_bytes = 0;
+ncclComm_t g_comm = nullptr;
+int g_comm_rank = 0, g_comm_size = 1;
+
+int g_stream_cap = 0;
+int g_stream_block = 256;
+int g_stream_nt = 1;
+int g_local_nt = -1;
+int g_stream_xcd = 0;
+int g_gather_mode = 0;
+int g_local_cap = 0;
+int g_stream_local = 1;
+int g_stream_kind = -1;
+int g_pipe_wgs_per_cu = 5;
+int g_num_cus = 256;
+int g_probe_mask = 1023;
+
+int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+int need_device() {
+    if (g_device < 0) return fail("spmv_hip_init() has not been called (or failed): no HIP device");
+    return 0;
+}
+
+// ------------------------------------------------------------------ device
+extern "C" int spmv_hip_set_tuning(const char *key, int value);
+extern "C" int spmv_hip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return n;
+}
+
+extern "C" int spmv_hip_init(int device) {
+    int n = spmv_hip_device_count();
+    if (n <= 0) return n < 0 ? -1 : fail("no HIP device visible");
+    if (device < 0 || device >= n) return fail("device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    if (g_stream && g_device != device) {
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    // SPMV_TUNING="key=value,key=value": same keys as spmv_hip_set_tuning (profiling aid)
+    if (const char *env = getenv("SPMV_TUNING")) {
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos &&
+                spmv_hip_set_tuning(item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1)) != 0)
+                return -1;
+            pos = end + 1;
+        }
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        g_num_cus = cus;
+    g_device = device;
+    return 0;
+}
+
+extern "C" int spmv_hip_shutdown(void) {
+    if (g_comm) {
+        (void)ncclCommDestroy(g_comm);
+        g_comm = nullptr;
+    }
+    if (g_flush_buf) {
+        (void)hipFree(g_flush_buf);
+        g_flush_buf = nullptr;
+        g_flush_bytes = 0;
+    }
+    if (g_stream) {
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    g_device = -1;
+    return 0;
+}
+
+extern "C" int spmv_hip_set_tuning(const char *key, int value) {
+    if (!key) return fail("set_tuning: NULL key");
+    if (!strcmp(key, "stream_cap")) {
+        if (value != 0 && value != 1024 && value != 2048 && value != 4096 && value != 8192)
+            return fail("set_tuning: stream_cap must be 0 (auto), 1024, 2048, 4096 or 8192");
+        g_stream_cap = value;
+    } else if (!strcmp(key, "stream_block")) {
+        if (value != 256 && value != 512 && value != 1024)
+            return fail("set_tuning: stream_block must be 256, 512 or 1024");
+        g_stream_block = value;
+    } else if (!strcmp(key, "stream_nt")) {
+        g_stream_nt = value != 0;
+    } else if (!strcmp(key, "stream_xcd")) {
+        if (value < -1) return fail("set_tuning: stream_xcd must be -1, 0 or a positive run length");
+        g_stream_xcd = value;
+    } else if (!strcmp(key, "probe_mask")) {
+        g_probe_mask = value;
+    } else if (!strcmp(key, "stream_kind")) {
+        if ((value < -1 || value > 5) && (value < 10 || value > 17))
+            return fail("set_tuning: stream_kind must be -1..5 (or 10..17 for the ablation probes)");
+        g_stream_kind = value;
+    } else if (!strcmp(key, "gather_mode")) {
+        if (value != 0 && value != 1) return fail("set_tuning: gather_mode must be 0 (broadcasts) or 1 (padded all-gather)");
+        g_gather_mode = value;
+    } else if (!strcmp(key, "local_nt")) {
+        if (value < -1 || value > 1) return fail("set_tuning: local_nt must be -1 (auto), 0 or 1");
+        g_local_nt = value;
+    } else if (!strcmp(key, "local_cap")) {
+        if (value != 0 && value != 1024 && value != 2048) return fail("set_tuning: local_cap must be 0, 1024 or 2048");
+        g_local_cap = value;  // takes effect at the next upload
+    } else if (!strcmp(key, "stream_local")) {
+        g_stream_local = value != 0;  // takes effect at the next upload
+    } else if (!strcmp(key, "pipe_wgs_per_cu")) {
+        if (value < 1 || value > 8) return fail("set_tuning: pipe_wgs_per_cu must be 1..8");
+        g_pipe_wgs_per_cu = value;
+    } else {
+        return fail("set_tuning: unknown key '%s'", key);
+    }
+    return 0;
+}
+
+extern "C" int spmv_hip_sync(void) {
+    if (need_device()) return -1;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" void *spmv_hip_stream(void) { return (void *)g_stream; }
+
+extern "C" const char *spmv_hip_last_error(void) { return g_error; }
+
+extern "C" int spmv_hip_device_name(char *buf, size_t len, int *compute_units, long long *hbm_bytes) {
+    if (need_device()) return -1;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    if (buf && len) snprintf(buf, len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (long long)prop.totalGlobalMem;
+    return 0;
+}
+
+extern "C" int spmv_hip_flush_cache(size_t bytes) {
+    if (need_device()) return -1;
+    if (bytes < 16) bytes = 16;
+    if (bytes > g_flush_bytes) {
+        if (g_flush_buf) HIP_TRY(hipFree(g_flush_buf));
+        g_flush_buf = nullptr;
+        g_flush_bytes = 0;
+        HIP_TRY(hipMalloc(&g_flush_buf, bytes));
+        HIP_TRY(hipMemset(g_flush_buf, 0, bytes));
+        g_flush_bytes = bytes;
+    }
+    hipLaunchKernelGGL(flush_kernel, dim3(2048), dim3(kBlock), 0, g_stream, (uint4 *)g_flush_buf,
+                       bytes / 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int spmv_hip_malloc(void **dptr, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+extern "C" int spmv_hip_free(void *dptr) {
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return 0;
+}
+extern "C" int spmv_hip_memcpy_h2d(void *dptr, const void *hptr, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipMemcpy(dptr, hptr, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int spmv_hip_memcpy_d2h(void *hptr, const void *dptr, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(hptr, dptr, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int spmv_hip_memset(void *dptr, int byte, size_t bytes) {
+    if (need_device()) return -1;
+    HIP_TRY(hipMemsetAsync(dptr, byte, bytes, g_stream));
+    return 0;
+}
+

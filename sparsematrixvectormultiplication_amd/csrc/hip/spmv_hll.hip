@@ -1,0 +1,485 @@
+// spmv_hll.hip -- HLL side of the C-ABI: the flat slab, its workgroup windows and x-window plan,
+// the device builder from a resident CSR matrix, launchers, timing.  Replaces the per-hack
+// allocations and launches of /root/reference/main_cuda.cu:369-455, :545-568, :613-637, :731-744.
+#include "spmv_internal.hpp"
+
+namespace {
+
+// first pass of the device builder (see hll_fill_from_csr in hll_kernels.hpp): per-hack maximum row length
+__global__ __launch_bounds__(kBlock) void hll_hack_maxnz(int M, int hacks, const int *__restrict__ row_ptr,
+                                                         int *__restrict__ maxnz) {
+    const int h = blockIdx.x * kBlock + threadIdx.x;
+    if (h >= hacks) return;
+    const int r0 = h * kHack, r1 = min(r0 + kHack, M);
+    int m = 0;
+    for (int r = r0; r < r1; ++r) m = max(m, row_ptr[r + 1] - row_ptr[r]);
+    maxnz[h] = m;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------- HLL
+namespace {
+
+// Cut the rows of the flat slab into workgroup windows for hll_lds: consecutive rows whose
+// slots, counted from the even slot at or below the first row's start, fit `cap` (at most
+// kStreamRowsCap rows).  A row that alone does not fit gets a window of its own.  Returns
+// the widest window (in slots, from its even base).
+long long hll_build_blocks(int M, int hacks, const long long *off, const int *mz, int cap,
+                           std::vector<int4> &desc) {
+    desc.clear();
+    (void)hacks;
+    long long widest = 0;
+    auto start_of = [&](int r) { return off[r / kHack] + (long long)(r % kHack) * mz[r / kHack]; };
+    int r = 0;
+    while (r < M) {
+        const long long s0 = start_of(r);
+        const long long base = s0 & ~1LL;
+        int r1 = r + 1;  // the first row is always taken (even if it alone exceeds cap)
+        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap) ++r1;
+        const long long span = start_of(r1 - 1) + mz[(r1 - 1) / kHack] - base;
+        if (r1 - r > 1 || span <= cap) widest = std::max(widest, span);
+        desc.push_back(int4{r, r1 - r, (int)(s0 & 0xffffffffLL), (int)(s0 >> 32)});
+        r = r1;
+    }
+    return widest;
+}
+
+}  // namespace
+
+namespace {
+
+// Windows for hll_lds_local: hll_build_blocks' cut at `cap` slots with the line limit on top
+// (see csr_build_local).  ja is the flat host slab.  false: keep the gather kernel.
+bool hll_build_local(int M, int N, const long long *off, const int *mz, const int *ja, long long slots_padded,
+                     int cap, int lines_max, const std::vector<int4> &baseline, LocalPlan &plan) {
+    constexpr int line_shift = 4;  // fp64: 16 per 128-byte line
+    const int total_lines = (int)(((long long)N + 15) >> line_shift);
+    std::vector<int> stamp((size_t)total_lines + 1, -1), rank((size_t)total_lines + 1, 0), cur;
+    plan.lcol.assign((size_t)slots_padded + kPad, 0);
+    plan.desc.clear();
+    plan.hll_ldesc.clear();
+    plan.lines.clear();
+    int widest = 0;
+    auto start_of = [&](int r) { return off[r / kHack] + (long long)(r % kHack) * mz[r / kHack]; };
+    int r = 0;
+    while (r < M) {
+        const long long s0 = start_of(r);
+        const long long base = s0 & ~1LL;
+        const int blk = (int)plan.desc.size();
+        cur.clear();
+        int r1 = r;
+        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap) {
+            const size_t before = cur.size();
+            const long long a = start_of(r1);
+            for (long long k = a; k < a + mz[r1 / kHack]; ++k) {
+                const int l = ja[k] >> line_shift;
+                if (stamp[l] != blk) {
+                    stamp[l] = blk;
+                    cur.push_back(l);
+                }
+            }
+            if ((int)cur.size() > lines_max) {
+                for (size_t k = before; k < cur.size(); ++k) stamp[cur[k]] = -1;
+                cur.resize(before);
+                break;
+            }
+            ++r1;
+        }
+        if (r1 == r) return false;  // a row that alone exceeds the stage or the line limit
+        if (cur.empty()) cur.push_back(0);  // rows without slots: the kernel still stages one line
+        std::sort(cur.begin(), cur.end());
+        for (size_t k = 0; k < cur.size(); ++k) rank[cur[k]] = (int)k;
+        for (long long k = s0; k < start_of(r1 - 1) + mz[(r1 - 1) / kHack]; ++k)
+            plan.lcol[k] = (unsigned short)((rank[ja[k] >> line_shift] << line_shift) | (ja[k] & 15));
+        plan.desc.push_back(int4{r, r1 - r, (int)(s0 & 0xffffffffLL), (int)(s0 >> 32)});
+        plan.hll_ldesc.push_back(int4{(int)plan.lines.size(), (int)cur.size(),
+                                      (int)(start_of(r1 - 1) + mz[(r1 - 1) / kHack] - base), 0});
+        plan.lines.insert(plan.lines.end(), cur.begin(), cur.end());
+        widest = std::max(widest, (int)cur.size());
+        r = r1;
+        if ((plan.desc.size() & 1023) == 0) {
+            const size_t plain = std::lower_bound(baseline.begin(), baseline.end(), r,
+                                                  [](const int4 &d, int row) { return d.x < row; }) -
+                                 baseline.begin();
+            if (plan.desc.size() > plain + plain / 5 + 16) return false;
+        }
+    }
+    if (plan.desc.size() > baseline.size() + baseline.size() / 5 + 1) return false;
+    plan.stage_lines = std::max(kLocalLineQuantum,
+                                (widest + kLocalLineQuantum - 1) / kLocalLineQuantum * kLocalLineQuantum);
+    plan.lines.insert(plan.lines.end(), (size_t)kLocalLinesMax, 0);
+    return true;
+}
+
+// offsets of the hacks in the flat slab: every hack starts on an even slot
+long long hll_offsets(int total_rows, const std::vector<int> &mz, std::vector<long long> &off,
+                      long long &true_slots) {
+    const int H = (int)mz.size();
+    off.assign((size_t)H + 1, 0);
+    true_slots = 0;
+    for (int h = 0; h < H; ++h) {
+        const int rows = (h == H - 1) ? total_rows - h * kHack : kHack;
+        const long long s = (long long)rows * mz[h];
+        true_slots += s;
+        off[h + 1] = off[h] + ((s + 1) & ~1LL);
+    }
+    return off[H];
+}
+
+// workgroup windows, small arrays and vectors of a handle whose JA / AS are already on the device
+int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<long long> &off,
+                      const std::vector<int> &mz, long long true_slots, bool upload_maxnz, const int *ja_host,
+                      int matrix_rows = -1, int row0 = 0) {
+    m->M_total = matrix_rows < 0 ? total_rows : matrix_rows;
+    m->row0 = row0;
+    const int H = (int)mz.size();
+    // like the CSR stream kernel: larger stages for matrices that have plenty of work
+    const int cap = true_slots >= (16LL << 20) ? kHllCap : kHllCap / 2;
+    std::vector<int4> hdesc;
+    const long long widest =
+        std::max<long long>(2 * kStreamUnit, hll_build_blocks(total_rows, H, off.data(), mz.data(), cap, hdesc));
+    m->M = total_rows;
+    m->N = N;
+    m->hacks = H;
+    m->slots = true_slots;
+    m->num_blocks = (int)hdesc.size();
+    m->stage_slots = (int)std::min<long long>(kHllCap, (widest + kStreamUnit - 1) / kStreamUnit * kStreamUnit);
+    int rc = 0;
+    if (!m->hack_off) rc |= upload_array(&m->hack_off, off.data(), off.size(), 0);
+    if (!rc && upload_maxnz) rc |= upload_array(&m->maxnz, mz.data(), mz.size(), 1);
+    if (!rc) rc |= upload_array(&m->hdesc, hdesc.data(), hdesc.size(), 1);
+    if (!rc) {
+        const size_t x_bytes = std::max<size_t>((size_t)N, 1) * sizeof(double) + kLineBytes;  // whole-line reads
+        hipError_t e = hipMalloc((void **)&m->x, x_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->y, std::max<size_t>((size_t)m->M_total, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(m->x, 0, x_bytes);
+        if (e == hipSuccess) e = hipMemset(m->y, 0, std::max<size_t>((size_t)m->M_total, 1) * sizeof(double));
+        if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
+    }
+    m->device_bytes = off.size() * 8 + mz.size() * 4 + ((size_t)off[H] + kPad) * 12 + hdesc.size() * 16 +
+                      ((size_t)N + (size_t)total_rows) * 8;
+    // the x-window kernel: windows of 2048 slots, 16-bit local JA (needs the slab on the host)
+    if (!rc && ja_host && g_stream_local && true_slots > 0) {
+        std::vector<int4> plain;
+        LocalPlan local;
+        hll_build_blocks(total_rows, H, off.data(), mz.data(), 2048, plain);
+        if (hll_build_local(total_rows, N, off.data(), mz.data(), ja_host, off[H], 2048, kLocalLinesMax, plain, local)) {
+            rc |= upload_array(&m->ldesc4, local.desc.data(), local.desc.size(), 1);
+            if (!rc) rc |= upload_array(&m->ldesc, local.hll_ldesc.data(), local.hll_ldesc.size(), 1);
+            if (!rc) rc |= upload_array(&m->lines, local.lines.data(), local.lines.size(), 0);
+            if (!rc) rc |= upload_array(&m->lja, local.lcol.data(), local.lcol.size(), 0);
+            if (!rc) {
+                m->local_blocks = (int)local.desc.size();
+                m->local_stage_lines = local.stage_lines;
+                m->local_lines = (long long)local.lines.size() - kLocalLinesMax;
+                m->device_bytes += local.desc.size() * 32 + local.lines.size() * 4 + local.lcol.size() * 2;
+            }
+        }
+    }
+    const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
+    m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
+    return rc;
+}
+
+}  // namespace
+
+// Hacks [hack0, hack1) of the matrix, i.e. rows [32 hack0, min(32 hack1, total_rows)): one
+// rank's share under the reference's hack partitioner (prepare_thread_distribution_hll,
+// src/hll_matrix.c:410-540); y stays full length, the kernels write this handle's rows.
+extern "C" int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
+                                        spmv_hll_dev **out) {
+    if (need_device()) return -1;
+    if (!hll || !out) return fail("hll_upload: NULL argument");
+    *out = nullptr;
+    if ((unsigned long long)N * 8 >= (1ull << 32))
+        return fail("hll_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
+    const int Hall = hll->num_blocks;
+    if (Hall != (total_rows + kHack - 1) / kHack)
+        return fail("hll_upload: %d hacks do not match %d rows", Hall, total_rows);
+    if (hack0 < 0 || hack1 < hack0 || hack1 > Hall)
+        return fail("hll_upload: bad hack range [%d, %d) of %d", hack0, hack1, Hall);
+    const int H = hack1 - hack0;
+    const int row0 = hack0 * kHack;
+    const int rows = std::min(hack1 * kHack, total_rows) - std::min(row0, total_rows);
+
+    std::vector<int> mz((size_t)H, 0);
+    for (int h = 0; h < H; ++h) {
+        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
+        const int expect = (hack0 + h == Hall - 1) ? total_rows - (hack0 + h) * kHack : kHack;
+        if (b->M != expect) return fail("hll_upload: hack %d holds %d rows, expected %d", hack0 + h, b->M, expect);
+        if (b->MAXNZ < 0 || (b->MAXNZ > 0 && (!b->JA || !b->AS)))
+            return fail("hll_upload: hack %d is malformed", hack0 + h);
+        mz[h] = b->MAXNZ;
+        const long long s = (long long)b->M * b->MAXNZ;
+        for (long long k = 0; k < s; ++k)
+            if ((unsigned)b->JA[k] >= (unsigned)N)
+                return fail("hll_upload: column index %d in hack %d is outside [0, %d)", b->JA[k], hack0 + h, N);
+    }
+    std::vector<long long> off;
+    long long true_slots = 0;
+    const long long S = hll_offsets(rows, mz, off, true_slots);
+    if (S > (1LL << 40)) return fail("hll_upload: %lld padded slots is unreasonable", S);
+
+    // pack every hack into one flat pair of host arrays, then two copies
+    std::vector<int> ja((size_t)S + kPad, 0);
+    std::vector<double> as((size_t)S + kPad, 0.0);
+    for (int h = 0; h < H; ++h) {
+        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
+        const size_t s = (size_t)b->M * b->MAXNZ;
+        if (!s) continue;
+        memcpy(&ja[(size_t)off[h]], b->JA, s * sizeof(int));
+        memcpy(&as[(size_t)off[h]], b->AS, s * sizeof(double));
+    }
+    spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
+    if (!m) return fail("hll_upload: out of host memory");
+    int rc = upload_array(&m->JA, ja.data(), ja.size(), 0);
+    if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
+    if (!rc) rc |= hll_finish_handle(m, rows, N, off, mz, true_slots, true, ja.data(), total_rows, row0);
+    if (rc) {
+        spmv_hip_hll_free(m);
+        return -1;
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
+    if (!hll) return fail("hll_upload: NULL argument");
+    return spmv_hip_hll_upload_part(hll, total_rows, N, 0, hll->num_blocks, out);
+}
+
+// HLL built on the device from a resident CSR matrix (whole matrix, fp64).
+extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out) {
+    if (need_device()) return -1;
+    if (!csr || !out) return fail("hll_from_csr: NULL argument");
+    *out = nullptr;
+    // a row block works when it starts on a hack boundary and ends on one (or at the last row)
+    if (csr->value_bytes != 8 || csr->row0 % kHack != 0 ||
+        ((csr->row0 + csr->M_local) % kHack != 0 && csr->row0 + csr->M_local != csr->M_total))
+        return fail("hll_from_csr: needs a whole fp64 CSR matrix (or a row block cut on hack boundaries)");
+    const int M = csr->M_local, N = csr->N, H = (M + kHack - 1) / kHack;
+    spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
+    if (!m) return fail("hll_from_csr: out of host memory");
+    std::vector<int> mz((size_t)H, 0);
+    std::vector<long long> off;
+    long long true_slots = 0;
+    int rc = 0;
+    do {
+        hipError_t e = hipMalloc((void **)&m->maxnz, ((size_t)H + 1) * sizeof(int));
+        if (e != hipSuccess) { rc = fail("hipMalloc(maxnz) failed: %s", hipGetErrorString(e)); break; }
+        if (H > 0) {
+            hipLaunchKernelGGL(hll_hack_maxnz, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, g_stream, M, H,
+                               csr->row_ptr, m->maxnz);
+            e = hipMemcpyAsync(mz.data(), m->maxnz, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, g_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+            if (e != hipSuccess) { rc = fail("hll_from_csr: maxnz pass failed: %s", hipGetErrorString(e)); break; }
+        }
+        const long long S = hll_offsets(M, mz, off, true_slots);  // H-sized scan on the host
+        if (S > (1LL << 40)) { rc = fail("hll_from_csr: %lld padded slots is unreasonable", S); break; }
+        e = hipMalloc((void **)&m->JA, ((size_t)S + kPad) * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&m->AS, ((size_t)S + kPad) * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(m->JA, 0, ((size_t)S + kPad) * sizeof(int), g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(m->AS, 0, ((size_t)S + kPad) * sizeof(double), g_stream);
+        if (e != hipSuccess) { rc = fail("hll_from_csr: slab allocation failed: %s", hipGetErrorString(e)); break; }
+        rc = upload_array(&m->hack_off, off.data(), off.size(), 0);
+        if (rc) break;
+        if (M > 0) {
+            hipLaunchKernelGGL((hll_fill_from_csr<double>), dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
+                               0, g_stream, M, csr->row_ptr, csr->col, (const double *)csr->val, m->hack_off,
+                               m->maxnz, m->JA, m->AS);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+            if (e != hipSuccess) { rc = fail("hll_from_csr: fill failed: %s", hipGetErrorString(e)); break; }
+        }
+        // the x-window plan is built on the host from the finished JA (one D2H copy of 4 bytes per slot)
+        std::vector<int> ja_host;
+        if (g_stream_local && S > 0) {
+            ja_host.resize((size_t)S);
+            e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
+        }
+        rc = hll_finish_handle(m, M, N, off, mz, true_slots, false, ja_host.empty() ? nullptr : ja_host.data(),
+                               csr->M_total, csr->row0);
+    } while (0);
+    if (rc) {
+        spmv_hip_hll_free(m);
+        return -1;
+    }
+    *out = m;
+    return 0;
+}
+
+// flat slab back to the host (tests; hosts that want the HLL arrays): hack_off[hacks + 1],
+// maxnz[hacks], JA / AS [hack_off[hacks]]; any pointer may be NULL
+extern "C" int spmv_hip_hll_download(const spmv_hll_dev *m, long long *hack_off, int *maxnz, int *JA, double *AS) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_download: NULL handle");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    std::vector<long long> off((size_t)m->hacks + 1);
+    HIP_TRY(hipMemcpy(off.data(), m->hack_off, off.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    if (hack_off) memcpy(hack_off, off.data(), off.size() * sizeof(long long));
+    if (maxnz && m->hacks) HIP_TRY(hipMemcpy(maxnz, m->maxnz, (size_t)m->hacks * sizeof(int), hipMemcpyDeviceToHost));
+    const size_t S = (size_t)off[m->hacks];
+    if (JA && S) HIP_TRY(hipMemcpy(JA, m->JA, S * sizeof(int), hipMemcpyDeviceToHost));
+    if (AS && S) HIP_TRY(hipMemcpy(AS, m->AS, S * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
+    if (!m) return;
+    (void)hipFree(m->hack_off);
+    (void)hipFree(m->maxnz);
+    (void)hipFree(m->JA);
+    (void)hipFree(m->AS);
+    (void)hipFree(m->hdesc);
+    (void)hipFree(m->ldesc4);
+    (void)hipFree(m->ldesc);
+    (void)hipFree(m->lines);
+    (void)hipFree(m->lja);
+    (void)hipFree(m->x);
+    (void)hipFree(m->y);
+    delete m;
+}
+
+extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
+    if (!m || !out) return fail("hll_info: NULL argument");
+    memset(out, 0, sizeof *out);
+    out->M_local = m->M;
+    out->M_total = m->M_total;
+    out->row0 = m->row0;
+    out->N = m->N;
+    out->value_bytes = 8;
+    out->auto_variant = m->auto_variant;
+    out->lanes_per_row = m->lanes_per_row;
+    out->stream_blocks = m->num_blocks;
+    out->slots = m->slots;
+    out->hacks = m->hacks;
+    // S (val + 4) + 12 H + val (M + N)
+    out->algo_bytes = m->slots * 12 + 12LL * m->hacks + 8LL * ((long long)m->M + m->N);
+    out->device_bytes = (long long)m->device_bytes;
+    out->local_blocks = m->local_blocks;
+    out->local_stage_lines = m->local_stage_lines;
+    out->local_lines = m->local_lines;
+    if (m->local_blocks > 0)
+        out->stream_bytes = m->slots * 10 + 4 * m->local_lines + 32LL * m->local_blocks + 12LL * m->hacks +
+                            8LL * ((long long)m->M + m->N);
+    return 0;
+}
+
+extern "C" void *spmv_hip_hll_x_ptr(spmv_hll_dev *m) { return m ? m->x : nullptr; }
+extern "C" void *spmv_hip_hll_y_ptr(spmv_hll_dev *m) { return m ? m->y : nullptr; }
+
+extern "C" int spmv_hip_hll_set_x(spmv_hll_dev *m, const double *x_host) {
+    if (need_device()) return -1;
+    if (!m || !x_host) return fail("hll_set_x: NULL argument");
+    HIP_TRY(hipMemcpyAsync(m->x, x_host, (size_t)m->N * 8, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int spmv_hip_hll_get_y(spmv_hll_dev *m, double *y_host) {
+    if (need_device()) return -1;
+    if (!m || !y_host) return fail("hll_get_y: NULL argument");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(y_host, m->y, (size_t)m->M_total * 8, hipMemcpyDeviceToHost));  // whole y, as for CSR
+    return 0;
+}
+
+namespace {
+
+template <int L>
+void launch_hll_vector(const spmv_hll_dev *m, const double *x, double *y, hipStream_t s) {
+    constexpr int rows = kBlock / L;
+    hipLaunchKernelGGL((hll_vector<double, L>), dim3((m->M + rows - 1) / rows), dim3(kBlock), 0, s,
+                       m->M, m->hack_off, m->maxnz, m->JA, m->AS, x, y);
+}
+
+}  // namespace
+
+int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_full, hipStream_t s) {
+    if (m->M == 0) return 0;
+    double *y = y_full + m->row0;  // the kernels number this handle's rows from 0
+    if (variant == SPMV_HLL_AUTO) variant = m->auto_variant;
+    switch (variant) {
+        case SPMV_HLL_THREAD_ROW:
+            hipLaunchKernelGGL((hll_thread_row<double>), dim3((m->M + kBlock - 1) / kBlock),
+                               dim3(kBlock), 0, s, m->M, m->hack_off, m->maxnz, m->JA, m->AS, x, y);
+            break;
+        case SPMV_HLL_SUBWAVE:
+            switch (m->lanes_per_row) {
+                case 2: launch_hll_vector<2>(m, x, y, s); break;
+                case 4: launch_hll_vector<4>(m, x, y, s); break;
+                case 8: launch_hll_vector<8>(m, x, y, s); break;
+                case 16: launch_hll_vector<16>(m, x, y, s); break;
+                default: launch_hll_vector<32>(m, x, y, s); break;
+            }
+            break;
+        case SPMV_HLL_LDS: {
+            if ((g_stream_kind == -1 || g_stream_kind == 5) && m->local_blocks > 0 &&
+                ((uintptr_t)x & (kLineBytes - 1)) == 0) {
+                const int lchunk = g_stream_xcd < 0 ? (m->local_blocks + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
+                const int lgrid = (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk);
+                const size_t llds = std::max((size_t)2048 * sizeof(double), (size_t)m->local_stage_lines * kLineBytes);
+                const bool lnt = g_local_nt < 0 ? m->slots * 10 > (128LL << 20) : g_local_nt != 0;
+                if (lnt)
+                    hipLaunchKernelGGL((hll_lds_local<double, true, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
+                                       m->lja, m->AS, x, y);
+                else
+                    hipLaunchKernelGGL((hll_lds_local<double, false, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
+                                       m->lja, m->AS, x, y);
+                break;
+            }
+            const size_t lds = 32 + ((size_t)m->stage_slots + 2) * sizeof(double);
+#define SPMV_HLL_LDS_LAUNCH(MAXU)                                                                  \
+    hipLaunchKernelGGL((hll_lds<double, true, MAXU>), dim3(m->num_blocks), dim3(kBlock), lds, s,    \
+                       m->stage_slots, m->hdesc, m->hack_off, m->maxnz, m->JA, m->AS, x, y)
+            const int units = m->stage_slots / kStreamUnit;
+            if (units <= 2) SPMV_HLL_LDS_LAUNCH(2);
+            else if (units <= 4) SPMV_HLL_LDS_LAUNCH(4);
+            else if (units <= 6) SPMV_HLL_LDS_LAUNCH(6);
+            else SPMV_HLL_LDS_LAUNCH(8);
+#undef SPMV_HLL_LDS_LAUNCH
+            break;
+        }
+        default:
+            return fail("unknown HLL variant %d", variant);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+
+
+extern "C" int spmv_hip_hll_run(spmv_hll_dev *m, int variant) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_run: NULL handle");
+    return hll_launch(m, variant, m->x, m->y, g_stream);
+}
+
+extern "C" int spmv_hip_hll_run_on(spmv_hll_dev *m, int variant, const void *d_x, void *d_y, void *stream) {
+    if (need_device()) return -1;
+    if (!m || !d_x || !d_y) return fail("hll_run_on: NULL argument");
+    return hll_launch(m, variant, (const double *)d_x, (double *)d_y, stream ? (hipStream_t)stream : g_stream);
+}
+
+extern "C" int spmv_hip_hll_time(spmv_hll_dev *m, int variant, int warmup, int iters, int zero_y,
+                                 float *ms_each) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_time: NULL handle");
+    return time_loop(
+        warmup, iters, ms_each, [&] { return hll_launch(m, variant, m->x, m->y, g_stream); },
+        [&]() -> int {
+            if (zero_y) HIP_TRY(hipMemsetAsync(m->y, 0, (size_t)m->M_total * 8, g_stream));
+            return 0;
+        });
+}
+
+extern "C" int spmv_hip_hll_time_graph(spmv_hll_dev *m, int variant, int iters, int replays, float *ms_per_iter) {
+    if (need_device()) return -1;
+    if (!m) return fail("hll_time_graph: NULL handle");
+    return graph_loop(iters, replays, ms_per_iter, [&] { return hll_launch(m, variant, m->x, m->y, g_stream); });
+}
+

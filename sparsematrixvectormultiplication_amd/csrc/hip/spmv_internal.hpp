@@ -1,0 +1,256 @@
+// spmv_internal.hpp -- what the translation units behind include/spmv_hip.h share: error
+// reporting, library state, the two device handles, upload helpers and the timing loops.
+// Not installed; nothing here is part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "csr_kernels.hpp"
+#include "hll_kernels.hpp"
+#include "spmv_hip.h"
+
+using namespace spmv;
+
+// ------------------------------------------------------------------ state (spmv_device.hip)
+extern int g_device;
+extern hipStream_t g_stream;
+extern ncclComm_t g_comm;
+extern int g_comm_rank, g_comm_size;
+
+// kernel tuning knobs (spmv_hip_set_tuning); defaults are the measured best
+extern int g_stream_cap;      // nnz staged per stream workgroup (fixed at upload); 0 = by matrix size
+extern int g_stream_block;    // threads per csr_stream workgroup
+extern int g_stream_nt;       // non-temporal loads for col/val in the gather stream kernels
+extern int g_local_nt;        // same for the x-window kernels: -1 = auto (off while the matrix fits the Infinity Cache)
+extern int g_stream_xcd;      // blocks per XCD run (xcd_chunked); 0 = default, -1 = one contiguous eighth per XCD
+extern int g_gather_mode;     // all-gatherv: 0 = one ncclBroadcast per owner in a group, 1 = padded ncclAllGather + scatter
+extern int g_local_cap;       // stage of the x-window plan: 0 = auto, 1024 or 2048
+extern int g_stream_local;    // build the x-window plan at upload when it pays
+extern int g_stream_kind;     // -1 = auto (x-window kernel when the matrix has a plan, else csr_stream), 5 = x-window,
+                              // 0 = csr_stream, 1 = row walk, 2 = pipe, 3 = persistent walk, 4 = ring, 10..17 = probes
+extern int g_pipe_wgs_per_cu; // resident workgroups per CU the persistent grids are sized for
+extern int g_num_cus;
+extern int g_probe_mask;      // csr_probe: table size - 1 (entries) of the folded gather
+
+int fail(const char *fmt, ...);  // records the message for spmv_hip_last_error(), returns -1
+int need_device();               // 0, or -1 when spmv_hip_init() has not succeeded
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t err__ = (expr);                                                        \
+        if (err__ != hipSuccess)                                                          \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, \
+                        __LINE__);                                                        \
+    } while (0)
+
+#define NCCL_TRY(expr)                                                                     \
+    do {                                                                                   \
+        ncclResult_t err__ = (expr);                                                       \
+        if (err__ != ncclSuccess)                                                          \
+            return fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(err__), __FILE__, \
+                        __LINE__);                                                         \
+    } while (0)
+
+constexpr int kPad = 8192 + 64;  // zero entries behind col/val: the stream / LDS kernels stage
+                                   // whole units without bounds tests (>= kStreamCapMax, kHllCap)
+
+template <typename T>
+int upload_array(T **dptr, const T *host, size_t count, size_t pad) {
+    HIP_TRY(hipMalloc((void **)dptr, (count + pad) * sizeof(T)));
+    if (count) HIP_TRY(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+    if (pad) HIP_TRY(hipMemset(*dptr + count, 0, pad * sizeof(T)));
+    return 0;
+}
+
+inline int pow2_floor(int v) {
+    int p = 1;
+    while (p * 2 <= v) p *= 2;
+    return p;
+}
+
+// ---------------------------------------------------------------- handles
+struct spmv_csr_dev {
+    int value_bytes = 8;
+    int M_local = 0, M_total = 0, N = 0, row0 = 0;
+    long long nz = 0;
+    int *row_ptr = nullptr;  // [M_local + 1], rebased to 0
+    int *col = nullptr;
+    void *val = nullptr;
+    void *x = nullptr;  // [N]
+    void *y = nullptr;  // [M_total]
+    // stream kernel
+    int4 *desc = nullptr;
+    int num_blocks = 0;
+    int4 *long_rows = nullptr;
+    int num_long = 0;
+    int4 *pieces = nullptr;
+    void *partial = nullptr;
+    int num_partial = 0;
+    int stream_cap = 2048;
+    bool ring_ok = false;  // blocks respect the ring kernel's row limit
+    // stream kernel with the x window in LDS (csr_stream_local): own blocks, 16-bit local columns
+    int4 *ldesc4 = nullptr;           // [local_blocks] like desc
+    int2 *ldesc = nullptr;            // [local_blocks] {first line in `lines`, line count}
+    int *lines = nullptr;             // x line ids, block after block, ascending inside a block
+    unsigned short *lcol = nullptr;   // [nz + pad] slot of each entry in its block's staged lines
+    int local_blocks = 0;             // 0: no plan (not profitable / not possible)
+    int local_stage_lines = 0;        // LDS stage: most lines any block lists, in steps of 32
+    int local_cap = 2048;
+    long long local_lines = 0;
+    // heuristics
+    int lanes_per_row = 16;
+    int auto_variant = SPMV_CSR_STREAM;
+    int max_row = 0;
+    size_t device_bytes = 0;
+};
+
+struct spmv_hll_dev {
+    int M = 0, N = 0, hacks = 0;  // rows / hacks HELD by this handle
+    int M_total = 0, row0 = 0;    // rows of the whole matrix (length of y), first global row (multiple of 32)
+    long long nz_hint = 0;
+    long long slots = 0;
+    long long *hack_off = nullptr;  // [hacks + 1]
+    int *maxnz = nullptr;           // [hacks]
+    int *JA = nullptr;
+    double *AS = nullptr;
+    int4 *hdesc = nullptr;  // [num_blocks] {first row, rows, first slot lo, first slot hi}
+    int num_blocks = 0;
+    int stage_slots = kHllCap;  // LDS stage of hll_lds: the largest workgroup, <= kHllCap
+    // hll_lds_local (x window in LDS): own windows, 16-bit local JA
+    int4 *ldesc4 = nullptr;
+    int4 *ldesc = nullptr;  // {first line, lines, slots of the window from its even base, 0}
+    int *lines = nullptr;
+    unsigned short *lja = nullptr;
+    int local_blocks = 0, local_stage_lines = 0;
+    long long local_lines = 0;
+    double *x = nullptr;
+    double *y = nullptr;
+    int lanes_per_row = 8;
+    int auto_variant = SPMV_HLL_LDS;
+    size_t device_bytes = 0;
+};
+
+// Blocks for csr_stream_local: csr_build_blocks' cut with one more limit, the number of
+// distinct x lines (1 << line_shift elements each) a block touches.  Fills, per block, the
+// ascending list of those lines and, per entry, its 16-bit slot (rank of its line in the
+// list * elements per line + column % elements per line).  Returns false when some row alone
+// needs more than lines_max lines, or when the line limit (rather than cap) decides so many
+// cuts that the blocks would run mostly empty: the caller then keeps the gather kernel.
+struct LocalPlan {
+    std::vector<unsigned char> split;  // CSR: rows handed to the split-row kernels (too many x lines)
+    std::vector<int4> desc;
+    std::vector<int4> hll_ldesc;  // HLL: {first line, lines, slots from the even base, 0}
+    std::vector<int2> ldesc;
+    std::vector<int> lines;
+    std::vector<unsigned short> lcol;
+    int stage_lines = 0;
+};
+
+// launchers the timing / exchange code calls across translation units
+int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s);
+int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_full, hipStream_t s);
+
+// ------------------------------------------------------------------ timing loops
+// events around each launch on the stream the kernel runs on
+template <typename Launch, typename Zero>
+int time_loop(int warmup, int iters, float *ms_each, Launch launch, Zero zero_y) {
+    // zero_y() is a no-op when the caller did not ask for the reference's memset
+    if (iters <= 0 || !ms_each) return fail("time: iters must be > 0 and ms_each non-NULL");
+    std::vector<hipEvent_t> ev((size_t)iters * 2);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = 0;
+    for (int i = 0; i < warmup && !rc; ++i) {
+        rc = zero_y();
+        if (!rc) rc = launch();
+    }
+    for (int i = 0; i < iters && !rc; ++i) {
+        rc = zero_y();
+        if (rc) break;
+        HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
+        rc = launch();
+        HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
+    }
+    if (!rc) {
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        for (int i = 0; i < iters; ++i) HIP_TRY(hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// `iters` back-to-back launches captured once into a hipGraph and replayed `replays` times:
+// what a launch-bound loop (small matrices: an 11 us kernel against ~6 us of per-launch host
+// work) costs per SpMV when the host is out of the way.  ms_per_iter = mean over the replays.
+template <typename Launch>
+int graph_loop(int iters, int replays, float *ms_per_iter, Launch launch) {
+    if (iters <= 0 || replays <= 0 || !ms_per_iter) return fail("time_graph: bad arguments");
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    hipError_t e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return fail("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+    for (int i = 0; i < iters && !rc; ++i) rc = launch();
+    e = hipStreamEndCapture(g_stream, &graph);
+    if (!rc && e != hipSuccess) rc = fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    if (!rc) {
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) rc = fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipGraphLaunch(exec, g_stream);  // warm-up replay
+        if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
+        for (int r = 0; r < replays && e == hipSuccess; ++r) e = hipGraphLaunch(exec, g_stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail("graph replay failed: %s", hipGetErrorString(e));
+        else *ms_per_iter = ms / ((float)replays * (float)iters);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+}
+
+// one step = this rank's kernel, then the all-gatherv of y (when a communicator exists)
+template <typename Launch>
+int step_loop(void *y, int value_bytes, const int *bounds, int warmup, int iters, float *ms_kernel,
+              float *ms_exchange, Launch launch) {
+    if (iters <= 0) return fail("step_time: iters must be > 0");
+    std::vector<hipEvent_t> ev((size_t)iters * 3);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = 0;
+    for (int i = -warmup; i < iters && !rc; ++i) {
+        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i], g_stream));
+        rc = launch();
+        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 1], g_stream));
+        if (!rc && g_comm) rc = spmv_hip_comm_allgatherv(y, bounds, value_bytes, g_stream);
+        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 2], g_stream));
+    }
+    if (!rc) {
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        for (int i = 0; i < iters; ++i) {
+            float a = 0, b = 0;
+            HIP_TRY(hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
+            HIP_TRY(hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
+            if (ms_kernel) ms_kernel[i] = a;
+            if (ms_exchange) ms_exchange[i] = b;
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
