@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "csr_kernels.hpp"
+#include "csr_kernels_experimental.hpp"
 #include "hll_kernels.hpp"
 #include "spmv_hip.h"
 
