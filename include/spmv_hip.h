@@ -216,6 +216,15 @@ int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *bounds, int 
 int spmv_hip_hll_step_time(spmv_hll_dev *m, int variant, const int *bounds, int warmup, int iters,
                            float *ms_kernel, float *ms_exchange);
 
+/* SURVEY 8(f) N4 -- iterated SpMV (power iteration as the skeleton): `iters` steps of
+ * x <- A x / ||A x||_2 from the handle's current x; y = A x on this rank's rows, all-gatherv(y) when a
+ * communicator exists (bounds = the row partition, else NULL), the 2-norm by a fixed-order device
+ * reduction that every rank repeats over the gathered y (same bits everywhere, no extra collective).
+ * No host synchronisation inside the loop; with one GPU and use_graph != 0 the loop is one hipGraph.
+ * Out: x normalised iterate, y last A x, *lambda last ||A x||_2, *ms_total device time of the loop. */
+int spmv_hip_csr_power_iterate(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_graph,
+                               double *lambda, float *ms_total);
+
 #ifdef __cplusplus
 }
 #endif

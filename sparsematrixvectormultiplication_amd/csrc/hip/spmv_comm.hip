@@ -254,11 +254,6 @@ extern "C" int spmv_hip_comm_autotune(void *d_y, const int *bounds, int value_by
     return 0;
 }
 
-namespace {
-
-
-}  // namespace
-
 extern "C" int spmv_hip_csr_step_time(spmv_csr_dev *m, int variant, const int *bounds, int warmup,
                                       int iters, float *ms_kernel, float *ms_exchange) {
     if (need_device()) return -1;
@@ -276,3 +271,136 @@ extern "C" int spmv_hip_hll_step_time(spmv_hll_dev *m, int variant, const int *b
                      [&] { return hll_launch(m, variant, m->x, m->y, g_stream); });
 }
 
+
+// ------------------------------------------------------------- iterated SpMV
+// SURVEY.md 8(f) N4.  The reference multiplies by a fixed x = 1 a hundred times; an iterated
+// method feeds y back into x, which is what makes the all-gatherv a real exchange step.  Power
+// iteration as the skeleton: y = A x on this rank's rows, all-gatherv(y), x = y / ||y||_2.  The
+// norm is computed by every rank over the whole gathered y with a fixed two-stage reduction
+// (deterministic, and identical on all ranks: no extra collective), everything stays on the
+// library stream with no host synchronisation inside the loop, so on one GPU the whole loop is
+// captured into a hipGraph.
+namespace {
+
+constexpr int kNormBlocks = 512;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void norm2_partial(const T *__restrict__ y, long long n, double *__restrict__ part) {
+    __shared__ double wave_sum[kBlock / 64];
+    double acc = 0;
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) {
+        const double v = (double)y[k];
+        acc += v * v;
+    }
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = wave_sum[0];
+        for (int w = 1; w < kBlock / 64; ++w) s += wave_sum[w];
+        part[blockIdx.x] = s;
+    }
+}
+
+// one workgroup: partial sums in fixed order -> norm[0] = ||y||_2, norm[1] = 1 / ||y||_2 (0 if y = 0)
+__global__ __launch_bounds__(kBlock) void norm2_finish(const double *__restrict__ part, int nparts, double *__restrict__ norm) {
+    __shared__ double wave_sum[kBlock / 64];
+    double acc = 0;
+    for (int k = threadIdx.x; k < nparts; k += kBlock) acc += part[k];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = wave_sum[0];
+        for (int w = 1; w < kBlock / 64; ++w) s += wave_sum[w];
+        const double nrm = sqrt(s);
+        norm[0] = nrm;
+        norm[1] = nrm > 0 ? 1.0 / nrm : 0.0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_into(const T *__restrict__ y, long long n, const double *__restrict__ norm,
+                                                     T *__restrict__ x) {
+    const double inv = norm[1];
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock)
+        x[k] = (T)((double)y[k] * inv);
+}
+
+template <typename T>
+int power_iterations(spmv_csr_dev *m, int variant, int iters, const int *bounds, double *d_part, double *d_norm) {
+    const long long n = m->M_total;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(kNormBlocks, (n + kBlock - 1) / kBlock));
+    for (int i = 0; i < iters; ++i) {
+        if (csr_launch_any(m, variant, m->x, m->y, g_stream)) return -1;
+        if (g_comm && bounds && spmv_hip_comm_allgatherv(m->y, bounds, m->value_bytes, g_stream)) return -1;
+        hipLaunchKernelGGL((norm2_partial<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)m->y, n, d_part);
+        hipLaunchKernelGGL(norm2_finish, dim3(1), dim3(kBlock), 0, g_stream, d_part, grid, d_norm);
+        hipLaunchKernelGGL((scale_into<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)m->y, n, d_norm, (T *)m->x);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// `iters` steps of x <- A x / ||A x||_2 starting from the handle's current x (square matrices;
+// every rank holds its row block, bounds = the row partition when a communicator exists, else NULL).
+// On return x is the normalised iterate, y the last A x, *lambda the last ||A x||_2 (the dominant
+// |eigenvalue| estimate), *ms_total the device time of the loop.  With one GPU and use_graph != 0
+// the loop is captured once and replayed as one hipGraph launch.
+extern "C" int spmv_hip_csr_power_iterate(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_graph,
+                                          double *lambda, float *ms_total) {
+    if (need_device()) return -1;
+    if (!m || iters <= 0) return fail("power_iterate: bad arguments");
+    if (m->M_total != m->N) return fail("power_iterate: needs a square matrix (%d x %d)", m->M_total, m->N);
+    if (g_comm && !bounds) return fail("power_iterate: a communicator exists, the row bounds are required");
+    double *d_part = nullptr, *d_norm = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int rc = 0;
+    do {
+        hipError_t e = hipMalloc((void **)&d_part, kNormBlocks * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_norm, 2 * sizeof(double));
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e != hipSuccess) { rc = fail("power_iterate: setup failed: %s", hipGetErrorString(e)); break; }
+        auto loop = [&]() {
+            return m->value_bytes == 8 ? power_iterations<double>(m, variant, iters, bounds, d_part, d_norm)
+                                       : power_iterations<float>(m, variant, iters, bounds, d_part, d_norm);
+        };
+        if (use_graph && !g_comm) {
+            e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
+            if (e != hipSuccess) { rc = fail("power_iterate: capture failed: %s", hipGetErrorString(e)); break; }
+            rc = loop();
+            e = hipStreamEndCapture(g_stream, &graph);
+            if (!rc && e != hipSuccess) rc = fail("power_iterate: capture failed: %s", hipGetErrorString(e));
+            if (!rc && (e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess)
+                rc = fail("power_iterate: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            if (rc) break;
+            e = hipEventRecord(e0, g_stream);
+            if (e == hipSuccess) e = hipGraphLaunch(exec, g_stream);
+        } else {
+            e = hipEventRecord(e0, g_stream);
+            if (e == hipSuccess) rc = loop();
+            if (rc) break;
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        double nrm[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpy(nrm, d_norm, sizeof nrm, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail("power_iterate: run failed: %s", hipGetErrorString(e)); break; }
+        if (lambda) *lambda = nrm[0];
+        if (ms_total) *ms_total = ms;
+    } while (0);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_part);
+    (void)hipFree(d_norm);
+    return rc;
+}

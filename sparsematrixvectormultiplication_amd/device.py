@@ -160,6 +160,22 @@ class CsrDevice(_Handle):
                "csr_time_graph")
         return float(ms.value)
 
+    def power_iterate(self, iters, variant=CSR_AUTO, bounds=None, use_graph=True):
+        """iters steps of x <- A x / ||A x||_2 on the device; returns (lambda, ms_total)."""
+        lam, ms = C.c_double(0), C.c_float(0)
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.int32)
+        _check(nat.lib().spmv_hip_csr_power_iterate(self.h, int(variant), int(iters),
+                                                    None if b is None else b.ctypes.data_as(nat.c_int_p),
+                                                    int(bool(use_graph)), C.byref(lam), C.byref(ms)),
+               "csr_power_iterate")
+        return float(lam.value), float(ms.value)
+
+    def get_x(self):
+        x = np.empty(self.N, dtype=self.dtype)
+        _check(nat.lib().spmv_hip_memcpy_d2h(x.ctypes.data_as(C.c_void_p), C.c_void_p(self.x_ptr), x.nbytes),
+               "memcpy_d2h")
+        return x
+
     def step_time(self, bounds, variant=CSR_AUTO, warmup=5, iters=95):
         """Multi-GPU step (SpMV + all-gatherv of y): per-step kernel and exchange ms."""
         b = np.ascontiguousarray(bounds, dtype=np.int32)
