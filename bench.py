@@ -205,6 +205,49 @@ def cpu_baseline(wl, cpu_iters):
                       f"({nnz} nnz) after 5 warm-ups, x = 1"}, y
 
 
+def cpu_baseline_hll(wl, cpu_iters):
+    """The reference's OpenMP HLL kernel (spmv_hll, src/hll_matrix.c:376-408) over its own hack
+    partition (prepare_thread_distribution_hll) on the host cores of this box; the compiled
+    reference when oracle/_ref is here (kind "reference"), else the restatement (kind "port")."""
+    import ctypes as C
+    from oracle.oracle import Oracle, Reference, have_reference
+    import sparsematrixvectormultiplication_amd as sp
+
+    hll, M, nnz = wl["hll"], wl["M"], int(wl["row_ptr"][-1])
+    x = np.ones(wl["N"])
+    starts, ends = sp.prepare_thread_distribution_hll(hll, min(HOST_CORES, max(1, hll.num_blocks)))
+    threads = len(starts)
+    y = np.zeros(hll.num_blocks * 32)
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    lib = Reference().L if have_reference() else Oracle().L
+    kind = "reference" if have_reference() else "port"
+    args = (hll.c.blocks, x.ctypes.data_as(dp), y.ctypes.data_as(dp), threads, starts.ctypes.data_as(ip),
+            ends.ctypes.data_as(ip))
+    t = time.perf_counter()
+    lib.spmv_hll(*args)
+    first = time.perf_counter() - t
+    iters = cpu_iters or int(max(5, min(95, 10.0 / max(first, 1e-4))))
+    for _ in range(min(5, iters)):
+        lib.spmv_hll(*args)
+    samples = []
+    for _ in range(iters):
+        t = time.perf_counter()
+        lib.spmv_hll(*args)
+        samples.append(time.perf_counter() - t)
+    mean = float(np.mean(samples))
+    ys = np.zeros(hll.num_blocks * 32)
+    serial = []
+    for _ in range(3):
+        t = time.perf_counter()
+        lib.spmv_hll_serial(hll.num_blocks, hll.c.blocks, x.ctypes.data_as(dp), ys.ctypes.data_as(dp))
+        serial.append(time.perf_counter() - t)
+    return {"value": round(2.0 * nnz / mean / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": kind,
+            "kernel": "spmv_hll (OpenMP over the reference's hack partition)", "ms_per_step": round(mean * 1e3, 4),
+            "serial_hll_gflops_1core": round(2.0 * nnz / min(serial) / 1e9, 3),
+            "sample": f"{iters} timed HLL SpMVs over the whole {wl['name']} matrix ({hll.slots} slots, "
+                      f"flops counted with the CSR nnz {nnz}) after 5 warm-ups, x = 1"}, y[:M]
+
+
 # ----------------------------------------------------------------- side measurements
 def side_measurement(sp, synth, which, steps, warmup):
     """cant-like CSR / HLL on this GPU (BASELINE configs[1], [2]) and the same FEM-shaped
@@ -507,9 +550,9 @@ def main():
                                      "allgatherv_max_over_ranks": round(float(per_rank[:, 2].max()), 5)}
 
     # CPU baseline + oracle check: rank 0, N = 1 only (bounded, ~10 s)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not hll_mode and vb == 8:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and vb == 8:
         wl["col_full"], wl["val_full"] = wl["col"], wl["val"]
-        cb, y_cpu = cpu_baseline(wl, args.cpu_iters)
+        cb, y_cpu = cpu_baseline_hll(wl, args.cpu_iters) if hll_mode else cpu_baseline(wl, args.cpu_iters)
         result["cpu_baseline"] = cb
         scale = max(float(np.max(np.abs(y_cpu))), 1e-300)
         result["parity_vs_cpu_reference"] = {"max_abs_diff_over_max_abs": float(np.max(np.abs(y_gpu - y_cpu)) / scale),
