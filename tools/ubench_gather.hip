@@ -62,9 +62,25 @@ double run(const char *name, const std::vector<unsigned> &pattern, size_t table_
     return cyc;
 }
 
-int main() {
+int main(int argc, char **argv) {
     srand(1);
     auto make = [](auto f) { std::vector<unsigned> p(8 * 64); for (int j = 0; j < 8; ++j) for (int l = 0; l < 64; ++l) p[j * 64 + l] = f(j, l); return p; };
+    if (argc > 1 && argv[1][0] == 'b') {
+        // "big": 64 different random lines per wave-instruction from tables that leave L2 (4 MiB per XCD)
+        // and then the 256 MiB Infinity Cache -- the access pattern of the uniform half of the power-law
+        // matrix's columns (BASELINE config 5: x is 64 MB of fp32)
+        auto rnd = make([](int, int) { return ((unsigned)rand() << 16) ^ (unsigned)rand(); });
+        for (int wpc : {16, 32}) {
+            printf("---- %d waves per CU, 64 random lines per wave-instruction\n", wpc);
+            for (size_t mib : {1, 4, 16, 64, 256, 1024}) {
+                char name[64];
+                snprintf(name, sizeof name, "float: random in %zu MiB", mib);
+                run<float>(name, rnd, mib << 18, wpc);
+            }
+            run<double>("double: random in 64 MiB", rnd, (size_t)64 << 17, wpc);
+        }
+        return 0;
+    }
     const size_t L2 = 1u << 18;   // 2 MiB of doubles: L2 resident
     const size_t L1 = 1u << 11;   // 16 KiB of doubles: L1 resident
     for (int wpc : {8, 16, 32}) {
