@@ -48,7 +48,9 @@ enum {
     SPMV_CSR_SUBWAVE = 3,    /* 2..32 lanes per row, picked from mean nnz/row
                                 (replaces spmv_csr_warp_shared_memory_kernel's slot:
                                 the x-cache idea is dropped) */
-    SPMV_CSR_STREAM = 4      /* nnz-balanced row blocks streamed through LDS */
+    SPMV_CSR_STREAM = 4      /* nnz-balanced row blocks streamed through LDS: csr_stream_local (x lines of
+                                the block staged in LDS, 16-bit local columns) when upload found an x-window
+                                plan for the matrix, else csr_stream (gathers); what AUTO resolves to */
 };
 
 /* HLL kernel selection.  1..3 answer cuda_src/hll_matrix.cu:346-479. */
@@ -56,7 +58,8 @@ enum {
     SPMV_HLL_AUTO = 0,
     SPMV_HLL_THREAD_ROW = 1, /* one lane per row over the row-major slab (spmv_hll_naive_kernel) */
     SPMV_HLL_SUBWAVE = 2,    /* a lane group per row                     (spmv_hll_warp_kernel) */
-    SPMV_HLL_LDS = 3         /* hack slabs staged through LDS            (spmv_hll_warp_shared_kernel_v1) */
+    SPMV_HLL_LDS = 3         /* row-aligned slab windows staged through LDS (spmv_hll_warp_shared_kernel_v1's
+                                slot): hll_lds_local with an x-window plan, else hll_lds; what AUTO resolves to */
 };
 
 typedef struct {
@@ -94,12 +97,23 @@ int spmv_hip_device_name(char *buf, size_t len, int *compute_units, long long *h
  * (answers clear_gpu_cache / clear_cache_kernel, cuda_src/utility.cu:140-175;
  * the reference's 64 MiB is far below MI355X's 256 MiB Infinity Cache). */
 int spmv_hip_flush_cache(size_t bytes);
-/* Kernel tuning knobs, for A/B measurements: "stream_cap" (2048 | 4096 | 8192 nnz staged
- * per csr_stream workgroup; read at upload), "stream_nt" (0/1 non-temporal
- * col/val loads), "stream_xcd" (blocks per XCD run: 0 dispatch order, -1 one contiguous eighth per XCD), "stream_block" (256 | 512 | 1024
- * threads), "stream_kind" (0 = one workgroup per block, products summed out of
- * LDS; 1 = rows walked out of LDS by neighbouring lanes; 2 = persistent,
- * double-buffered product kernel; 3 = persistent row walk), "pipe_wgs_per_cu" (grid of kind 2). */
+/* Kernel tuning knobs, for A/B measurements (defaults are the measured best; also settable through the
+ * environment, SPMV_TUNING="key=value,...", read by spmv_hip_init):
+ *   read at upload
+ *     "stream_cap"    0 (auto) | 1024 | 2048 | 4096 | 8192 entries staged per workgroup of the gather stream
+ *                     kernel; a value other than the x-window stage skips the x-window plan
+ *     "stream_local"  1 | 0   build the x-window plan (16-bit local columns + line lists) when the matrix allows
+ *     "local_cap"     0 (auto = 2048) | 1024 | 2048   stage of the x-window kernels
+ *   read at launch
+ *     "stream_kind"   -1 (auto: x-window kernel when the handle has a plan, else csr_stream) | 5 x-window |
+ *                     0 csr_stream | 1 row walk | 2 persistent pipe | 3 persistent row walk | 4 loader/consumer
+ *                     ring | 10..17 ablation probes (measurement only)
+ *     "stream_nt" 0/1, "local_nt" -1 (auto) / 0 / 1   non-temporal hint on the streamed arrays
+ *     "stream_xcd"    blocks per XCD run: 0 default (16 for the x-window kernels, dispatch order otherwise),
+ *                     -1 one contiguous eighth per XCD, n > 0 runs of n
+ *     "stream_block"  256 | 512 | 1024 threads (csr_stream at 4096 / 8192), "pipe_wgs_per_cu" 1..8,
+ *     "probe_mask"    table size - 1 of the folded gather probe
+ *     "gather_mode"   all-gatherv: 0 grouped broadcasts | 1 padded all-gather + scatter (see spmv_hip_comm_autotune) */
 int spmv_hip_set_tuning(const char *key, int value);
 
 /* raw device buffers, for callers that keep x / y on the device themselves */
