@@ -131,6 +131,11 @@ int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
                         const double *values, int row0, int row1, spmv_csr_dev **out);
 int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx,
                             const float *values, int row0, int row1, spmv_csr_dev **out);
+/* Host-only self-check of what upload precomputes (workgroup blocks, split rows, the x-window plan: 16-bit
+ * local columns + per-block line lists) for a CSR structure; needs no device.  0 when every invariant holds;
+ * stats[6] (optional): gather blocks, x-window blocks (0 = no plan), listed lines, widest block's lines, long
+ * rows, rows handed to the split-row kernels because they alone touch too many lines. */
+int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, int *stats);
 /* convenience over the kept struct */
 int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **out);
 void spmv_hip_csr_free(spmv_csr_dev *m);

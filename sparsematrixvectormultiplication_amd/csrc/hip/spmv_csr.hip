@@ -238,6 +238,100 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
 
 }  // namespace
 
+// Host-only self-check of the upload-time preprocessing (no device needed): builds the workgroup
+// blocks and the x-window plan for the given CSR structure exactly as upload does and verifies
+// their invariants -- blocks and split rows partition the rows, every block fits the stage and
+// lists at most kLocalLinesMax strictly ascending lines, every entry's 16-bit slot leads back to
+// its column.  stats (optional, 6 ints): gather blocks, x-window blocks (0 = no plan), listed
+// lines, widest block's lines, long rows, rows handed over because of the line limit.
+extern "C" int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
+                                       int *stats) {
+    if (M < 0 || N < 0 || !row_ptr || (value_bytes != 4 && value_bytes != 8)) return fail("plan_check: bad arguments");
+    const long long nz = row_ptr[M];
+    if (nz > 0 && !col_idx) return fail("plan_check: col_idx is NULL");
+    for (int r = 0; r < M; ++r)
+        if (row_ptr[r + 1] < row_ptr[r]) return fail("plan_check: row_ptr decreases at row %d", r);
+    for (long long e = 0; e < nz; ++e)
+        if ((unsigned)col_idx[e] >= (unsigned)N) return fail("plan_check: column %d outside [0, %d)", col_idx[e], N);
+    const int cap = 2048, shift = value_bytes == 8 ? 4 : 5, mask = (1 << shift) - 1;
+    std::vector<int4> desc, pieces, long_rows;
+    LocalPlan plan;
+    csr_build_blocks(M, row_ptr, cap, kStreamRowsCap, desc, pieces, long_rows);
+    const bool have = nz > 0 && csr_build_local(M, N, row_ptr, col_idx, nz, cap, kStreamRowsCap, shift,
+                                                kLocalLinesMax, desc, plan);
+    csr_build_blocks(M, row_ptr, cap, kStreamRowsCap, desc, pieces, long_rows, have ? &plan.split : nullptr);
+    // gather blocks + long rows partition the rows
+    std::vector<unsigned char> seen((size_t)M, 0);
+    auto claim = [&](int r0, int n, const char *what) {
+        for (int r = r0; r < r0 + n; ++r) {
+            if (r < 0 || r >= M || seen[r]) return fail("plan_check: row %d claimed twice or out of range (%s)", r, what);
+            seen[r] = 1;
+        }
+        return 0;
+    };
+    for (const int4 &d : desc) {
+        if (claim(d.x, d.z, "gather block")) return -1;
+        if (d.z <= 0 || d.z > kStreamRowsCap || d.y != row_ptr[d.x] || d.w != row_ptr[d.x + d.z] ||
+            d.w - (d.y & kBaseMask) > cap)
+            return fail("plan_check: gather block at row %d is malformed", d.x);
+    }
+    int split_rows = 0;
+    for (const int4 &l : long_rows) {
+        if (claim(l.x, 1, "long row")) return -1;
+        long long covered = 0;
+        for (int k = 0; k < l.z; ++k) {
+            const int4 &pc = pieces[(size_t)l.y + k];
+            if (pc.x != l.x || pc.z - pc.y <= 0 || pc.z - pc.y > kLongPiece) return fail("plan_check: bad piece of row %d", l.x);
+            covered += pc.z - pc.y;
+        }
+        if (covered != row_ptr[l.x + 1] - row_ptr[l.x]) return fail("plan_check: pieces of row %d do not cover it", l.x);
+        const bool by_length = row_ptr[l.x + 1] - row_ptr[l.x] > cap - 3;
+        if (!by_length && !(have && plan.split[l.x])) return fail("plan_check: row %d is split without a reason", l.x);
+        split_rows += !by_length;
+    }
+    for (int r = 0; r < M; ++r)
+        if (!seen[r]) return fail("plan_check: row %d belongs to no block", r);
+    int widest = 0;
+    if (have) {
+        std::fill(seen.begin(), seen.end(), 0);
+        if (plan.desc.size() != plan.ldesc.size()) return fail("plan_check: descriptor arrays differ in length");
+        for (size_t b = 0; b < plan.desc.size(); ++b) {
+            const int4 &d = plan.desc[b];
+            const int2 &ld = plan.ldesc[b];
+            if (claim(d.x, d.z, "x-window block")) return -1;
+            if (d.z <= 0 || d.z > kStreamRowsCap || d.y != row_ptr[d.x] || d.w != row_ptr[d.x + d.z] ||
+                d.w - (d.y & kBaseMask) > cap)
+                return fail("plan_check: x-window block at row %d is malformed", d.x);
+            if (ld.y < 1 || ld.y > kLocalLinesMax || ld.x < 0 || (size_t)ld.x + ld.y > plan.lines.size())
+                return fail("plan_check: line list of block %zu is malformed", b);
+            for (int k = 1; k < ld.y; ++k)
+                if (plan.lines[ld.x + k] <= plan.lines[ld.x + k - 1]) return fail("plan_check: lines of block %zu not ascending", b);
+            for (int e = d.y; e < d.w; ++e) {
+                const int slot = plan.lcol[e], rank = slot >> shift;
+                if (rank >= ld.y || plan.lines[ld.x + rank] != (col_idx[e] >> shift) || (slot & mask) != (col_idx[e] & mask))
+                    return fail("plan_check: entry %d (column %d) has slot %d, which is not its column", e, col_idx[e], slot);
+            }
+            widest = std::max(widest, ld.y);
+        }
+        // every row is in an x-window block, long, or split because of its lines
+        for (int r = 0; r < M; ++r) {
+            const bool by_length = row_ptr[r + 1] - row_ptr[r] > cap - 3;
+            if (!seen[r] && !by_length && !plan.split[r]) return fail("plan_check: row %d is in no x-window block", r);
+            if (seen[r] && (by_length || plan.split[r])) return fail("plan_check: row %d is both in a block and split", r);
+        }
+        if (plan.stage_lines < widest || plan.stage_lines % kLocalLineQuantum) return fail("plan_check: bad stage size");
+    }
+    if (stats) {
+        stats[0] = (int)desc.size();
+        stats[1] = have ? (int)plan.desc.size() : 0;
+        stats[2] = have ? (int)plan.lines.size() - kLocalLinesMax : 0;
+        stats[3] = widest;
+        stats[4] = (int)long_rows.size();
+        stats[5] = split_rows;
+    }
+    return 0;
+}
+
 extern "C" int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
                                    const double *values, int row0, int row1, spmv_csr_dev **out) {
     return csr_upload_impl<double>(M, N, row_ptr, col_idx, values, row0, row1, out);
@@ -486,11 +580,6 @@ extern "C" int spmv_hip_csr_run_on(spmv_csr_dev *m, int variant, const void *d_x
     return csr_launch_any(m, variant, d_x, d_y, stream ? (hipStream_t)stream : g_stream);
 }
 
-namespace {
-
-
-}  // namespace
-
 extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, int zero_y,
                                  float *ms_each) {
     if (need_device()) return -1;
@@ -502,11 +591,6 @@ extern "C" int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int i
             return 0;
         });
 }
-
-namespace {
-
-
-}  // namespace
 
 extern "C" int spmv_hip_csr_time_graph(spmv_csr_dev *m, int variant, int iters, int replays, float *ms_per_iter) {
     if (need_device()) return -1;

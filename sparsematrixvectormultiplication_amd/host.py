@@ -246,6 +246,18 @@ def partition_rows(row_ptr, parts):
     return bounds
 
 
+def csr_plan_check(M, N, row_ptr, col_idx, value_bytes=8):
+    """Host-only self-check of the upload-time plan (spmv_hip_csr_plan_check); returns its stats."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    stats = np.zeros(6, dtype=np.int32)
+    if nat.lib().spmv_hip_csr_plan_check(int(M), int(N), _ip(row_ptr), _ip(col_idx), int(value_bytes),
+                                         _ip(stats)) != 0:
+        raise ValueError(nat.lib().spmv_hip_last_error().decode())
+    return dict(zip(("gather_blocks", "local_blocks", "lines", "widest_lines", "long_rows", "split_rows"),
+                    (int(v) for v in stats)))
+
+
 def partition_hacks(hll: "HllHost", parts):
     """Hack bounds [0 = b0 <= ... <= b_parts = num_blocks] for `parts` GPUs (reference K8 greedy)."""
     bounds = np.zeros(parts + 1, dtype=np.int32)

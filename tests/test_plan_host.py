@@ -1,0 +1,57 @@
+"""The upload-time preprocessing (workgroup blocks, split rows, x-window plan) checked on the
+host, without a GPU: spmv_hip_csr_plan_check rebuilds what upload builds and verifies every
+invariant the kernels rely on (tests/ run it over the shapes the GPU parity tests use)."""
+import numpy as np
+import pytest
+
+import sparsematrixvectormultiplication_amd as sp
+from _util import banded_csr, random_csr
+from conftest import GOLDEN_CASES, golden_path
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_plan_invariants_on_golden_matrices(name):
+    csr = sp.convert_in_csr(sp.read_matrix_market(golden_path(name)))
+    for vb in (8, 4):
+        st = sp.csr_plan_check(csr.M, csr.N, csr.row_ptr, csr.col_idx, vb)
+        assert st["gather_blocks"] + st["long_rows"] > 0 or csr.M == 0
+
+
+@pytest.mark.parametrize("mean,band,empty,far", [(3, 40, 0.4, 0.0), (27, 200, 0.0, 0.3), (300, 900, 0.0, 0.0),
+                                                 (1500, 1900, 0.0, 0.0)])
+def test_plan_invariants_on_banded_matrices(mean, band, empty, far):
+    rng = np.random.default_rng(mean)
+    row_ptr, col, _ = banded_csr(rng, 4001, 5603, mean, band, empty, far_frac=far)
+    for vb in (8, 4):
+        st = sp.csr_plan_check(4001, 5603, row_ptr, col, vb)
+        assert st["local_blocks"] > 0 and st["widest_lines"] <= 256 and st["split_rows"] == 0
+        assert st["lines"] >= st["local_blocks"]
+
+
+def test_plan_is_refused_or_partial_where_it_should_be():
+    rng = np.random.default_rng(5)
+    row_ptr, col, _ = random_csr(rng, 3000, 40000, 30, 60, 0.0)       # scattered: no plan
+    assert sp.csr_plan_check(3000, 40000, row_ptr, col)["local_blocks"] == 0
+    # banded + a few wild rows: plan kept, wild rows split
+    row_ptr, col, _ = banded_csr(rng, 3000, 40000, 30, 200)
+    lens = np.diff(row_ptr).astype(np.int64)
+    cols = [col[row_ptr[r]:row_ptr[r + 1]] for r in range(3000)]
+    for r in (5, 1500, 2999):
+        cols[r] = np.sort(rng.choice(40000, 500, replace=False)).astype(np.int32)
+        lens[r] = 500
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    st = sp.csr_plan_check(3000, 40000, rp, np.concatenate(cols))
+    assert st["local_blocks"] > 0 and st["split_rows"] == 3 and st["long_rows"] == 3
+    # unsorted and repeated columns inside rows are fine
+    shuffled = np.concatenate([rng.permutation(c) for c in cols])
+    st2 = sp.csr_plan_check(3000, 40000, rp, shuffled)
+    assert st2["local_blocks"] == st["local_blocks"] and st2["lines"] == st["lines"]
+    with pytest.raises(ValueError, match="outside"):
+        sp.csr_plan_check(2, 2, np.array([0, 1, 2], np.int32), np.array([0, 7], np.int32))
+
+
+def test_plan_on_the_cant_like_matrix():
+    from sparsematrixvectormultiplication_amd import synth
+    M, row_ptr, col, _ = synth.fem_like(synth.FEM_GRID, 1)
+    st = sp.csr_plan_check(M, M, row_ptr, col)
+    assert st["local_blocks"] == st["gather_blocks"] and st["widest_lines"] <= 64 and st["long_rows"] == 0
