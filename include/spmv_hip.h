@@ -164,6 +164,9 @@ int spmv_hip_csr_time(spmv_csr_dev *m, int variant, int warmup, int iters, int z
 /* ---- HLL --------------------------------------------------------------- */
 /* total_rows = the matrix' M (the last hack may hold fewer than 32 rows). */
 int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out);
+/* Host-only self-check of what HLL upload precomputes (slab offsets, workgroup windows, x-window plan); needs no
+ * device.  stats[4] (optional): gather windows, x-window windows (0 = no plan), listed lines, widest window's lines. */
+int spmv_hip_hll_plan_check(const HLLMatrix *hll, int total_rows, int N, int *stats);
 /* One rank's share: hacks [hack0, hack1) = rows [32 hack0, min(32 hack1, total_rows)).  y keeps the
  * full length; the kernels write this handle's rows (HLL is split on hack boundaries). */
 int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,

@@ -184,6 +184,75 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
 
 }  // namespace
 
+// Host-only self-check of what HLL upload precomputes (flat slab offsets, workgroup windows, the
+// x-window plan); needs no device.  stats (optional, 4 ints): gather windows, x-window windows
+// (0 = no plan), listed lines, widest window's lines.
+extern "C" int spmv_hip_hll_plan_check(const HLLMatrix *hll, int total_rows, int N, int *stats) {
+    if (!hll || total_rows < 0 || N < 0) return fail("hll_plan_check: bad arguments");
+    const int H = hll->num_blocks;
+    if (H != (total_rows + kHack - 1) / kHack) return fail("hll_plan_check: %d hacks do not match %d rows", H, total_rows);
+    std::vector<int> mz((size_t)H, 0);
+    for (int h = 0; h < H; ++h) {
+        const ELLPACKBlock *b = &hll->blocks[h];
+        if (b->MAXNZ < 0 || (b->MAXNZ > 0 && (!b->JA || !b->AS))) return fail("hll_plan_check: hack %d is malformed", h);
+        if (b->M != ((h == H - 1) ? total_rows - h * kHack : kHack)) return fail("hll_plan_check: hack %d has %d rows", h, b->M);
+        mz[h] = b->MAXNZ;
+    }
+    std::vector<long long> off;
+    long long true_slots = 0;
+    const long long S = hll_offsets(total_rows, mz, off, true_slots);
+    std::vector<int> ja((size_t)S + kPad, 0);
+    for (int h = 0; h < H; ++h) {
+        const size_t s = (size_t)hll->blocks[h].M * mz[h];
+        for (size_t k = 0; k < s; ++k) {
+            if ((unsigned)hll->blocks[h].JA[k] >= (unsigned)N) return fail("hll_plan_check: column outside [0, %d) in hack %d", N, h);
+            ja[(size_t)off[h] + k] = hll->blocks[h].JA[k];
+        }
+    }
+    auto start_of = [&](int r) { return off[r / kHack] + (long long)(r % kHack) * mz[r / kHack]; };
+    std::vector<int4> plain;
+    LocalPlan plan;
+    hll_build_blocks(total_rows, H, off.data(), mz.data(), 2048, plain);
+    int next = 0;
+    for (const int4 &d : plain) {  // windows tile the rows in order
+        if (d.x != next || d.y <= 0) return fail("hll_plan_check: gather window at row %d out of order", d.x);
+        next = d.x + d.y;
+    }
+    if (next != total_rows) return fail("hll_plan_check: gather windows end at row %d of %d", next, total_rows);
+    const bool have = true_slots > 0 && hll_build_local(total_rows, N, off.data(), mz.data(), ja.data(), S, 2048,
+                                                        kLocalLinesMax, plain, plan);
+    int widest = 0;
+    if (have) {
+        next = 0;
+        for (size_t b = 0; b < plan.desc.size(); ++b) {
+            const int4 &d = plan.desc[b];
+            const int4 &ld = plan.hll_ldesc[b];
+            if (d.x != next || d.y <= 0 || d.y > kStreamRowsCap) return fail("hll_plan_check: x-window window %zu out of order", b);
+            next = d.x + d.y;
+            const long long s0 = ((long long)d.w << 32) | (unsigned)d.z, base = s0 & ~1LL;
+            const long long end = start_of(d.x + d.y - 1) + mz[(d.x + d.y - 1) / kHack];
+            if (s0 != start_of(d.x) || ld.z != (int)(end - base) || ld.z > 2048) return fail("hll_plan_check: window %zu has a wrong extent", b);
+            if (ld.y < 1 || ld.y > kLocalLinesMax) return fail("hll_plan_check: window %zu lists %d lines", b, ld.y);
+            for (int k = 1; k < ld.y; ++k)
+                if (plan.lines[ld.x + k] <= plan.lines[ld.x + k - 1]) return fail("hll_plan_check: lines of window %zu not ascending", b);
+            for (long long k = s0; k < end; ++k) {
+                const int slot = plan.lcol[k], rank = slot >> 4;
+                if (rank >= ld.y || plan.lines[ld.x + rank] != (ja[k] >> 4) || (slot & 15) != (ja[k] & 15))
+                    return fail("hll_plan_check: slot %lld (column %d) maps to %d", k, ja[k], slot);
+            }
+            widest = std::max(widest, ld.y);
+        }
+        if (next != total_rows) return fail("hll_plan_check: x-window windows end at row %d of %d", next, total_rows);
+    }
+    if (stats) {
+        stats[0] = (int)plain.size();
+        stats[1] = have ? (int)plan.desc.size() : 0;
+        stats[2] = have ? (int)plan.lines.size() - kLocalLinesMax : 0;
+        stats[3] = widest;
+    }
+    return 0;
+}
+
 // Hacks [hack0, hack1) of the matrix, i.e. rows [32 hack0, min(32 hack1, total_rows)): one
 // rank's share under the reference's hack partitioner (prepare_thread_distribution_hll,
 // src/hll_matrix.c:410-540); y stays full length, the kernels write this handle's rows.

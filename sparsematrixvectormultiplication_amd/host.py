@@ -258,6 +258,14 @@ def csr_plan_check(M, N, row_ptr, col_idx, value_bytes=8):
                     (int(v) for v in stats)))
 
 
+def hll_plan_check(hll: "HllHost"):
+    """Host-only self-check of the HLL upload-time plan (spmv_hip_hll_plan_check); returns its stats."""
+    stats = np.zeros(4, dtype=np.int32)
+    if nat.lib().spmv_hip_hll_plan_check(C.byref(hll.c), int(hll.M), int(hll.N), _ip(stats)) != 0:
+        raise ValueError(nat.lib().spmv_hip_last_error().decode())
+    return dict(zip(("gather_windows", "local_windows", "lines", "widest_lines"), (int(v) for v in stats)))
+
+
 def partition_hacks(hll: "HllHost", parts):
     """Hack bounds [0 = b0 <= ... <= b_parts = num_blocks] for `parts` GPUs (reference K8 greedy)."""
     bounds = np.zeros(parts + 1, dtype=np.int32)

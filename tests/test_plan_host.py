@@ -55,3 +55,26 @@ def test_plan_on_the_cant_like_matrix():
     M, row_ptr, col, _ = synth.fem_like(synth.FEM_GRID, 1)
     st = sp.csr_plan_check(M, M, row_ptr, col)
     assert st["local_blocks"] == st["gather_blocks"] and st["widest_lines"] <= 64 and st["long_rows"] == 0
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_hll_plan_invariants_on_golden_matrices(name):
+    hll = sp.convert_to_hll(sp.read_matrix_market(golden_path(name)))
+    st = sp.hll_plan_check(hll)
+    assert st["gather_windows"] >= (1 if hll.M else 0)
+
+
+@pytest.mark.parametrize("mean,band,empty,far", [(3, 40, 0.4, 0.0), (27, 200, 0.0, 0.3), (300, 900, 0.0, 0.0)])
+def test_hll_plan_invariants_on_banded_matrices(mean, band, empty, far):
+    from _util import coo_from_csr
+    rng = np.random.default_rng(100 + mean)
+    M, N = 2051, 2600
+    row_ptr, col, val = banded_csr(rng, M, N, mean, band, empty, far_frac=far)
+    r, c, v = coo_from_csr(row_ptr, col, val, rng)
+    hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, N, r, c, v))
+    st = sp.hll_plan_check(hll)
+    assert st["local_windows"] > 0 and st["widest_lines"] <= 256
+    # scattered columns: no plan, the check of the plain windows still passes
+    row_ptr, col, val = random_csr(rng, 500, 30000, 40, 80, 0.0)
+    r, c, v = coo_from_csr(row_ptr, col, val, rng)
+    assert sp.hll_plan_check(sp.convert_to_hll(sp.PreMatrix.from_arrays(500, 30000, r, c, v)))["local_windows"] == 0
