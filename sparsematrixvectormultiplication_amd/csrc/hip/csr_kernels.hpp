@@ -195,6 +195,57 @@ __device__ __forceinline__ void sum_rows_from_lds(const T *prod, const int *__re
     }
 }
 
+// Row extents of every pass of the row-sum phase, loaded at kernel start so that they ride along
+// with the stream instead of costing a dependent global round trip per pass.  More than one pass
+// only happens with one lane per row (a block of > BLOCK / 2 rows: matrices with very short rows).
+// PRELOAD = false keeps only the first pass in registers (12 VGPRs fewer: the difference between 7
+// and 6 resident workgroups per CU for the x-window kernel) and fetches later passes when it gets
+// there; the launcher picks PRELOAD for handles whose mean row is shorter than stage / BLOCK.
+template <int BLOCK, bool PRELOAD>
+struct row_extents {
+    static constexpr int kPasses = PRELOAD ? kStreamRowsCap / BLOCK : 1;
+    int lo[kPasses], hi[kPasses];
+};
+
+template <int BLOCK, bool PRELOAD>
+__device__ __forceinline__ row_extents<BLOCK, PRELOAD> load_row_extents(const int *__restrict__ row_ptr, int r0,
+                                                                        int nrows, int lanes, int base) {
+    row_extents<BLOCK, PRELOAD> e;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < row_extents<BLOCK, PRELOAD>::kPasses; ++p) {
+        const int row = p == 0 ? t / lanes : p * BLOCK + t;  // passes > 0 exist only for lanes == 1
+        // raw row_ptr values: nothing is computed from them here, so nothing waits for them before
+        // the stream loads have been issued (base is subtracted where they are used)
+        e.lo[p] = e.hi[p] = base;
+        if ((p == 0 || lanes == 1) && row < nrows) {
+            e.lo[p] = row_ptr[r0 + row];
+            e.hi[p] = row_ptr[r0 + row + 1];
+        }
+    }
+    return e;
+}
+
+template <typename T, int BLOCK, bool PRELOAD>
+__device__ __forceinline__ void sum_rows_from_lds(const T *prod, const int *__restrict__ row_ptr, T *__restrict__ y,
+                                                  int r0, int nrows, int base, int lanes,
+                                                  const row_extents<BLOCK, PRELOAD> &e) {
+    if constexpr (PRELOAD) {
+        const int t = threadIdx.x;
+        const int my_lane = t % lanes;
+#pragma unroll
+        for (int p = 0; p < row_extents<BLOCK, PRELOAD>::kPasses; ++p) {
+            const int row = p == 0 ? t / lanes : p * BLOCK + t;
+            if (p > 0 && (lanes != 1 || p * BLOCK >= nrows)) break;  // wave-uniform
+            T acc = lds_strided_sum(prod, e.lo[p] - base, e.hi[p] - base, my_lane, lanes);
+            acc = group_sum_rt(acc, lanes);
+            if (my_lane == 0 && row < nrows) y[r0 + row] = acc;
+        }
+    } else {
+        sum_rows_from_lds<T, BLOCK>(prod, row_ptr, y, r0, nrows, base, lanes, e.lo[0] - base, e.hi[0] - base);
+    }
+}
+
 // NU units of one block, straight-line: all (col, val) pair loads, then all gathers, then the
 // products into LDS.  The unit count of a block is wave-uniform, so the caller's switch is scalar.
 template <typename T, bool NT, int BLOCK, int NU>
@@ -233,9 +284,9 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chun
                                                     const int *__restrict__ col,
                                                     const T *__restrict__ val,
                                                     const T *__restrict__ x, T *__restrict__ y) {
+    using V2 = typename vec2<T>::type;
     constexpr int kUnit = 2 * BLOCK;  // entries one pass of the workgroup covers
     constexpr int kUnits = CAP / kUnit;
-    static_assert(kUnits >= 1 && kUnits <= 8, "stage of 1..8 units");
     __shared__ T prod[CAP];
 
     const int b = xcd_chunked(blockIdx.x, xcd_chunk);
@@ -254,22 +305,94 @@ __global__ __launch_bounds__(BLOCK) void csr_stream(int num_blocks, int xcd_chun
     }
 
     const int e_first = base + 2 * t;
-    // only the units the block really has (a block cut short by its row cap -- matrices with very
-    // short rows -- or by the end of the matrix streams no padding), each count straight-line
-    const int units = (d.w - base + kUnit - 1) / kUnit;  // wave-uniform, 0..kUnits
-    switch (units) {
-        case 1: stream_stage<T, NT, BLOCK, 1>(prod, col, val, x, e_first); break;
-        case 2: if constexpr (kUnits >= 2) stream_stage<T, NT, BLOCK, 2>(prod, col, val, x, e_first); break;
-        case 3: if constexpr (kUnits >= 3) stream_stage<T, NT, BLOCK, 3>(prod, col, val, x, e_first); break;
-        case 4: if constexpr (kUnits >= 4) stream_stage<T, NT, BLOCK, 4>(prod, col, val, x, e_first); break;
-        case 5: if constexpr (kUnits >= 5) stream_stage<T, NT, BLOCK, 5>(prod, col, val, x, e_first); break;
-        case 6: if constexpr (kUnits >= 6) stream_stage<T, NT, BLOCK, 6>(prod, col, val, x, e_first); break;
-        case 7: if constexpr (kUnits >= 7) stream_stage<T, NT, BLOCK, 7>(prod, col, val, x, e_first); break;
-        case 8: if constexpr (kUnits >= 8) stream_stage<T, NT, BLOCK, 8>(prod, col, val, x, e_first); break;
-        default: break;  // a block of empty rows
+    const int units = (d.w - base + kUnit - 1) / kUnit;  // wave-uniform
+    if (units == kUnits) {
+        // a full block: everything straight-line
+        v2i c[kUnits];
+        V2 v[kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kUnit));
+            v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+        }
+        T xv[2 * kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            xv[2 * u] = gather(x, c[u].x);
+            xv[2 * u + 1] = gather(x, c[u].y);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            V2 p;
+            p.x = v[u].x * xv[2 * u];
+            p.y = v[u].y * xv[2 * u + 1];
+            *reinterpret_cast<V2 *>(&prod[u * kUnit + 2 * t]) = p;
+        }
+    } else {
+        // a block cut short by its row cap or by the end of the matrix: only the
+        // units it really has (scalar loop, no wasted traffic)
+        for (int u = 0; u < units; ++u) {
+            const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(col + e_first + u * kUnit));
+            const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+            V2 p;
+            p.x = v.x * gather(x, c.x);
+            p.y = v.y * gather(x, c.y);
+            *reinterpret_cast<V2 *>(&prod[u * kUnit + 2 * t]) = p;
+        }
     }
     __syncthreads();
     sum_rows_from_lds<T, BLOCK>(prod, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);
+}
+
+// csr_stream for matrices with very short rows (mean row < stage / 256): most blocks are then cut by
+// the row cap, not by the stage, so (1) every unit count gets straight-line staging instead of the
+// one-unit-at-a-time loop csr_stream keeps for its rare short blocks, and (2) the row extents of all
+// passes of the row-sum phase (up to 1024 rows, one lane each) are loaded up front.  Road-like
+// 3-per-row matrix: 316 -> 236 us; kept apart from csr_stream because the extra code costs the full
+// blocks of gather-bound matrices 4 % (profiles/r1b_ab_short_row_kernel.txt).
+template <typename T, bool NT, int CAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void csr_stream_short(int num_blocks, int xcd_chunk,
+                                                    const int4 *__restrict__ desc,
+                                                    const int *__restrict__ row_ptr,
+                                                    const int *__restrict__ col,
+                                                    const T *__restrict__ val,
+                                                    const T *__restrict__ x, T *__restrict__ y) {
+    constexpr int kUnit = 2 * BLOCK;  // entries one pass of the workgroup covers
+    constexpr int kUnits = CAP / kUnit;
+    static_assert(kUnits >= 1 && kUnits <= 8, "stage of 1..8 units");
+    __shared__ T prod[CAP];
+
+    const int b = xcd_chunked(blockIdx.x, xcd_chunk);
+    if (b >= num_blocks) return;  // whole workgroup leaves together
+    const int t = threadIdx.x;
+    const int4 d = desc[b];
+    const int r0 = d.x, nrows = d.z;
+    const int base = d.y & kBaseMask;
+
+    // row extents go out first so they are back early
+    const int lanes = lanes_for_rows<BLOCK>(nrows);
+    const row_extents<BLOCK, true> ext = load_row_extents<BLOCK, true>(row_ptr, r0, nrows, lanes, base);
+
+    const int e_first = base + 2 * t;
+    // only the units the block really has (a block cut short by its row cap -- matrices with very
+    // short rows -- or by the end of the matrix streams no padding)
+    const int units = (d.w - base + kUnit - 1) / kUnit;  // wave-uniform, 0..kUnits
+    if (units == kUnits) {
+        stream_stage<T, NT, BLOCK, kUnits>(prod, col, val, x, e_first);  // the common case first
+    } else {
+        switch (units) {
+            case 1: if constexpr (kUnits > 1) stream_stage<T, NT, BLOCK, 1>(prod, col, val, x, e_first); break;
+            case 2: if constexpr (kUnits > 2) stream_stage<T, NT, BLOCK, 2>(prod, col, val, x, e_first); break;
+            case 3: if constexpr (kUnits > 3) stream_stage<T, NT, BLOCK, 3>(prod, col, val, x, e_first); break;
+            case 4: if constexpr (kUnits > 4) stream_stage<T, NT, BLOCK, 4>(prod, col, val, x, e_first); break;
+            case 5: if constexpr (kUnits > 5) stream_stage<T, NT, BLOCK, 5>(prod, col, val, x, e_first); break;
+            case 6: if constexpr (kUnits > 6) stream_stage<T, NT, BLOCK, 6>(prod, col, val, x, e_first); break;
+            case 7: if constexpr (kUnits > 7) stream_stage<T, NT, BLOCK, 7>(prod, col, val, x, e_first); break;
+            default: break;  // a block of empty rows
+        }
+    }
+    __syncthreads();
+    sum_rows_from_lds<T, BLOCK, true>(prod, row_ptr, y, r0, nrows, base, lanes, ext);
 }
 
 // --------------------------------------------------------- stream, local x
@@ -338,52 +461,6 @@ __device__ __forceinline__ void local_stage_full(T *stage, const int *__restrict
     for (int u = 0; u < kUnits; ++u) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = v[u];
 }
 
-// The same for a block that is not full (cut short by the row cap, the line cap or the end of the
-// matrix): `units` and `rounds` are wave-uniform run-time counts, so the loads sit behind scalar
-// branches and the waits are conservative -- two memory round trips (list, then x lines together
-// with the stream) instead of the full block's overlapped one, but never one per unit.
-template <typename T, bool NT, int CAP>
-__device__ __forceinline__ void local_stage_partial(T *stage, const int *__restrict__ my_lines, int nlines, int rounds,
-                                                    int units, const unsigned short *__restrict__ lcol,
-                                                    const T *__restrict__ val, const T *__restrict__ x, int e_first) {
-    using V2 = typename vec2<T>::type;
-    constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit, kRounds = kLocalLinesMax / kLocalLineQuantum;
-    const int t = threadIdx.x;
-    int line[kRounds];
-#pragma unroll
-    for (int k = 0; k < kRounds; ++k)
-        if (k < rounds) line[k] = my_lines[min(k * kLocalLineQuantum + (t >> 3), nlines - 1)];
-    uint4 xl[kRounds];
-#pragma unroll
-    for (int k = 0; k < kRounds; ++k)
-        if (k < rounds) {
-            const unsigned off = (unsigned)line[k] * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
-            xl[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
-        }
-    unsigned c[kUnits];
-    V2 v[kUnits];
-#pragma unroll
-    for (int u = 0; u < kUnits; ++u)
-        if (u < units) {
-            c[u] = stream_load<NT>(reinterpret_cast<const unsigned *>(lcol + e_first + u * kUnit));
-            v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
-        }
-#pragma unroll
-    for (int k = 0; k < kRounds; ++k)
-        if (k < rounds) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) = xl[k];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kUnits; ++u)
-        if (u < units) {
-            v[u].x *= stage[c[u] & 0xffffu];
-            v[u].y *= stage[c[u] >> 16];
-        }
-    __syncthreads();  // the products take the place of the staged lines
-#pragma unroll
-    for (int u = 0; u < kUnits; ++u)
-        if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = v[u];
-}
-
 template <typename T, bool NT, int CAP>
 __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int xcd_chunk,
                                                            const int4 *__restrict__ desc,
@@ -393,7 +470,8 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
                                                            const unsigned short *__restrict__ lcol,
                                                            const T *__restrict__ val,
                                                            const T *__restrict__ x, T *__restrict__ y) {
-        constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
+        using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
     // one LDS stage, used twice: first the x lines of the block, then (after every lane has
     // gathered its x values into registers) the CAP products.  max(CAP values, staged lines).
     extern __shared__ __attribute__((aligned(16))) unsigned char local_smem[];
@@ -408,6 +486,8 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
     const int base = d.y & kBaseMask;
 
     const int lanes = lanes_for_rows<kBlock>(nrows);
+    // (only the first pass's row extents are loaded up front: keeping all passes in registers, as
+    // csr_stream_short does, costs 12 VGPRs = one resident workgroup per CU here)
     int seg_lo = 0, seg_hi = 0;
     if (t / lanes < nrows) {
         seg_lo = row_ptr[r0 + t / lanes];
@@ -430,7 +510,28 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
             default: local_stage_full<T, NT, CAP, 8>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
         }
     } else {
-        local_stage_partial<T, NT, CAP>(stage, my_lines, ld.y, rounds, units, lcol, val, x, e_first);
+        // a block cut short (row cap, line cap, end of the matrix): plain loops
+        for (int k = 0; k < rounds; ++k) {
+            const int line = my_lines[min(k * kLocalLineQuantum + (t >> 3), ld.y - 1)];
+            const unsigned off = (unsigned)line * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) =
+                *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+        }
+        __syncthreads();
+        V2 p[kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            if (u < units) {
+                const unsigned c = stream_load<NT>(reinterpret_cast<const unsigned *>(lcol + e_first + u * kUnit));
+                p[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+                p[u].x *= stage[c & 0xffffu];
+                p[u].y *= stage[c >> 16];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u)
+            if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = p[u];
     }
     __syncthreads();
     sum_rows_from_lds<T, kBlock>(stage, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
                                                         const unsigned short *__restrict__ lja,
                                                         const T *__restrict__ AS,
                                                         const T *__restrict__ x, T *__restrict__ y) {
-        constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
+        using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
     extern __shared__ __align__(16) unsigned char hll_local_lds[];
     T *stage = reinterpret_cast<T *>(hll_local_lds);  // x lines first, then the products
 
@@ -280,7 +281,27 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
             default: local_stage_full<T, NT, CAP, 8>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
         }
     } else {
-        local_stage_partial<T, NT, CAP>(stage, my_lines, ld.y, rounds, units, wj, wa, x, 2 * t);
+        for (int k = 0; k < rounds; ++k) {
+            const int line = my_lines[min(k * kLocalLineQuantum + (t >> 3), ld.y - 1)];
+            const unsigned off = (unsigned)line * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) =
+                *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+        }
+        __syncthreads();
+        V2 p[kUnits];
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            if (u < units) {
+                const unsigned c = stream_load<NT>(reinterpret_cast<const unsigned *>(wj + 2 * t + u * kUnit));
+                p[u] = stream_load<NT>(reinterpret_cast<const V2 *>(wa + 2 * t + u * kUnit));
+                p[u].x *= stage[c & 0xffffu];
+                p[u].y *= stage[c >> 16];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u)
+            if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = p[u];
     }
     __syncthreads();
     for (int first = 0; first < nrows; first += rows_per_pass) {

@@ -528,10 +528,17 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
 #undef SPMV_WALK
                 } else if (cap == 1024) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 1024, 256);
+                } else if (cap == 2048 && m->nz < (long long)m->M_local * (2048 / kBlock)) {
+                    if (g_stream_nt) hipLaunchKernelGGL((csr_stream_short<T, true, 2048, 256>), dim3(grid_blocks), dim3(256), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                    else hipLaunchKernelGGL((csr_stream_short<T, false, 2048, 256>), dim3(grid_blocks), dim3(256), 0, s, m->num_blocks, chunk, SPMV_ARGS);
                 } else if (cap == 2048) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 2048, 256);
                 } else if (cap == 4096 && blk == 512) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 4096, 512);
+                } else if (cap == 4096 && m->nz < (long long)m->M_local * (4096 / kBlock)) {
+                    // short rows: blocks of up to 1024 rows, row extents of all passes loaded up front
+                    if (g_stream_nt) hipLaunchKernelGGL((csr_stream_short<T, true, 4096, 256>), dim3(grid_blocks), dim3(256), 0, s, m->num_blocks, chunk, SPMV_ARGS);
+                    else hipLaunchKernelGGL((csr_stream_short<T, false, 4096, 256>), dim3(grid_blocks), dim3(256), 0, s, m->num_blocks, chunk, SPMV_ARGS);
                 } else if (cap == 4096) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 4096, 256);
                 } else if (blk == 1024) {
