@@ -277,7 +277,7 @@ def side_measurement(sp, synth, which, steps, warmup):
                 "auto": {"gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
                          "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
                          "pct_of_8TBs": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9 / 80.0, 2),
-                         "kernel": "csr_stream_local" if info["local_blocks"] else "csr_stream",
+                         "kernel": ("csr_stream", "csr_stream_local", "csr_stream_short")[info["stream_kernel"]],
                          "format_bytes": info["stream_bytes"] or info["algo_bytes"],
                          "us": round(float(ms.mean()) * 1e3, 2)}}
     M, row_ptr, col, val = synth.fem_like()
@@ -296,7 +296,7 @@ def side_measurement(sp, synth, which, steps, warmup):
                              "us_median": round(float(np.median(ms)) * 1e3, 2)}
             # the launch-bound case: 20 launches replayed from one hipGraph, wall time per SpMV
             out["stream"]["us_per_spmv_graph_replay"] = round(dev.time_graph(sp.CSR_STREAM, 20, 10) * 1e3, 2)
-        out["stream"]["kernel"] = "csr_stream_local" if info["local_blocks"] else "csr_stream"
+        out["stream"]["kernel"] = ("csr_stream", "csr_stream_local", "csr_stream_short")[info["stream_kernel"]]
         return {"workload": "cant-like fp64 CSR (M=62451, nnz=%d; Infinity-Cache resident)" % nnz,
                 "algo_bytes": info["algo_bytes"], **out}
     from _bench_util import coo_of
@@ -509,8 +509,9 @@ def main():
         achieved = per_rank[slow, 3] / (k_ms * 1e-3) / 1e9
         # the STREAM variant runs csr_stream_local (x lines staged in LDS, 16-bit local columns)
         # when upload found a plan for the matrix, else csr_stream (gathers)
-        stream_name = "csr_stream_local" if (not hll_mode and info.get("local_blocks", 0) > 0) else "csr_stream"
-        kernel_name = (("hll_lds_local" if info.get("local_blocks", 0) > 0 else "hll_lds") if hll_mode else
+        from sparsematrixvectormultiplication_amd.device import CSR_STREAM_KERNELS, HLL_LDS_KERNELS
+        stream_name = CSR_STREAM_KERNELS[info["stream_kernel"]] if not hll_mode else None
+        kernel_name = (HLL_LDS_KERNELS[info["stream_kernel"]] if hll_mode else
                        {0: stream_name, 1: "csr_thread_row", 2: "csr_vector<64,2>", 3: "csr_vector<L,1>",
                         4: stream_name}[variant if variant else info["auto_variant"]])
         moved = float(per_rank[slow, 5]) if kernel_name.endswith("_local") else float(per_rank[slow, 3])

@@ -83,6 +83,8 @@ typedef struct {
     long long stream_bytes;/* CSR: bytes the x-window kernel really streams from HBM:
                               nz (val + 2) + 4 lines + 24 blocks + 4 (M + 1) + val (M + N);
                               0 without a plan (then algo_bytes is what moves)    */
+    int stream_kernel;     /* which kernel STREAM / LDS (and AUTO) launches with default tuning:
+                              CSR 0 csr_stream, 1 csr_stream_local, 2 csr_stream_short; HLL 0 hll_lds, 1 hll_lds_local */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */

@@ -50,7 +50,7 @@ class DevInfo(C.Structure):
                 ("lanes_per_row", C.c_int), ("stream_blocks", C.c_int), ("long_rows", C.c_int),
                 ("slots", C.c_longlong), ("hacks", C.c_int), ("algo_bytes", C.c_longlong),
                 ("device_bytes", C.c_longlong), ("local_blocks", C.c_int), ("local_stage_lines", C.c_int),
-                ("local_lines", C.c_longlong), ("stream_bytes", C.c_longlong)]
+                ("local_lines", C.c_longlong), ("stream_bytes", C.c_longlong), ("stream_kernel", C.c_int)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -178,7 +178,7 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
                 M, N, nz, hi.slots, ci.algo_bytes, hi.algo_bytes, r_stream.time,
                 r_stream.flops / 1e9, gb_c, gb_c / 80.0, r_stream.err.mean_rel_err, h_lds.time,
                 h_lds.flops / 1e9, gb_h, gb_h / 80.0,
-                ci.local_blocks > 0 ? "csr_stream_local" : "csr_stream",
+                ci.stream_kernel == 1 ? "csr_stream_local" : (ci.stream_kernel == 2 ? "csr_stream_short" : "csr_stream"),
                 ci.local_blocks > 0 ? ci.stream_bytes : ci.algo_bytes,
                 hi.local_blocks > 0 ? "hll_lds_local" : "hll_lds",
                 hi.local_blocks > 0 ? hi.stream_bytes : hi.algo_bytes);

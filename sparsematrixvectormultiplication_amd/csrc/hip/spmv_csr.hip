@@ -385,6 +385,9 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->local_blocks = m->local_blocks;
     out->local_stage_lines = m->local_stage_lines;
     out->local_lines = m->local_lines;
+    out->stream_kernel = m->local_blocks > 0 ? 1
+                         : ((m->stream_cap == 4096 || m->stream_cap == 2048) && m->M_local > 0 &&
+                            m->nz < (long long)m->M_local * (m->stream_cap / kBlock)) ? 2 : 0;
     if (m->local_blocks > 0)
         out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
                             4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;

@@ -428,6 +428,7 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     out->algo_bytes = m->slots * 12 + 12LL * m->hacks + 8LL * ((long long)m->M + m->N);
     out->device_bytes = (long long)m->device_bytes;
     out->local_blocks = m->local_blocks;
+    out->stream_kernel = m->local_blocks > 0 ? 1 : 0;
     out->local_stage_lines = m->local_stage_lines;
     out->local_lines = m->local_lines;
     if (m->local_blocks > 0)
