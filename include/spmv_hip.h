@@ -102,10 +102,11 @@ int spmv_hip_flush_cache(size_t bytes);
 /* Kernel tuning knobs, for A/B measurements (defaults are the measured best; also settable through the
  * environment, SPMV_TUNING="key=value,...", read by spmv_hip_init):
  *   read at upload
- *     "stream_cap"    0 (auto) | 1024 | 2048 | 4096 | 8192 entries staged per workgroup of the gather stream
+ *     "stream_cap"    0 (auto) | 1024 | 2048 | 3072 | 4096 | 8192 entries staged per workgroup of the gather stream
  *                     kernel; a value other than the x-window stage skips the x-window plan
  *     "stream_local"  1 | 0   build the x-window plan (16-bit local columns + line lists) when the matrix allows
- *     "local_cap"     0 (auto = 2048) | 1024 | 2048   stage of the x-window kernels
+ *     "local_cap"     0 (auto = 2048) | 1024 | 2048 | 3072   stage of the x-window kernels (3072: +0.5..3 % on the
+ *                     nlpkkt-like matrix depending on the box, -8 % on the cant-like one)
  *   read at launch
  *     "stream_kind"   -1 (auto: x-window kernel when the handle has a plan, else csr_stream) | 5 x-window |
  *                     0 csr_stream | 1 row walk | 2 persistent pipe | 3 persistent row walk | 4 loader/consumer

@@ -486,6 +486,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     // (cant-like, 53 MB: 10.9 us without it, 11.7 us with; fem-large: 160 vs 151 us)
                     const bool lnt = g_local_nt < 0 ? m->nz * (long long)(sizeof(T) + 2) > (128LL << 20) : g_local_nt != 0;
                     if (m->local_cap == 1024) { if (lnt) SPMV_LOCAL(true, 1024); else SPMV_LOCAL(false, 1024); }
+                    else if (m->local_cap == 3072) { if (lnt) SPMV_LOCAL(true, 3072); else SPMV_LOCAL(false, 3072); }
                     else { if (lnt) SPMV_LOCAL(true, 2048); else SPMV_LOCAL(false, 2048); }
 #undef SPMV_LOCAL
                 } else if (g_stream_kind == 4 && m->ring_ok) {
@@ -531,6 +532,8 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
 #undef SPMV_WALK
                 } else if (cap == 1024) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 1024, 256);
+                } else if (cap == 3072) {
+                    SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 3072, 256);
                 } else if (cap == 2048 && m->nz < (long long)m->M_local * (2048 / kBlock)) {
                     if (g_stream_nt) hipLaunchKernelGGL((csr_stream_short<T, true, 2048, 256>), dim3(grid_blocks), dim3(256), 0, s, m->num_blocks, chunk, SPMV_ARGS);
                     else hipLaunchKernelGGL((csr_stream_short<T, false, 2048, 256>), dim3(grid_blocks), dim3(256), 0, s, m->num_blocks, chunk, SPMV_ARGS);

@@ -120,8 +120,8 @@ extern "C" int spmv_hip_shutdown(void) {
 extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     if (!key) return fail("set_tuning: NULL key");
     if (!strcmp(key, "stream_cap")) {
-        if (value != 0 && value != 1024 && value != 2048 && value != 4096 && value != 8192)
-            return fail("set_tuning: stream_cap must be 0 (auto), 1024, 2048, 4096 or 8192");
+        if (value != 0 && value != 1024 && value != 2048 && value != 3072 && value != 4096 && value != 8192)
+            return fail("set_tuning: stream_cap must be 0 (auto), 1024, 2048, 3072, 4096 or 8192");
         g_stream_cap = value;
     } else if (!strcmp(key, "stream_block")) {
         if (value != 256 && value != 512 && value != 1024)
@@ -145,7 +145,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         if (value < -1 || value > 1) return fail("set_tuning: local_nt must be -1 (auto), 0 or 1");
         g_local_nt = value;
     } else if (!strcmp(key, "local_cap")) {
-        if (value != 0 && value != 1024 && value != 2048) return fail("set_tuning: local_cap must be 0, 1024 or 2048");
+        if (value != 0 && value != 1024 && value != 2048 && value != 3072)
+            return fail("set_tuning: local_cap must be 0, 1024, 2048 or 3072");
         g_local_cap = value;  // takes effect at the next upload
     } else if (!strcmp(key, "stream_local")) {
         g_stream_local = value != 0;  // takes effect at the next upload

@@ -28,7 +28,7 @@ for cap in (2048, 4096, 8192):
     d.set_x(x)
     devs[cap] = d
 set_tuning("stream_cap", 0)
-for lc in (1024, 2048):
+for lc in (1024, 2048, 3072):
     set_tuning("local_cap", lc)
     d = sp.CsrDevice(M, M, row_ptr, col, val)
     d.set_x(x)
@@ -43,6 +43,8 @@ arms = [(f"prod cap={cap} block={blk}", dict(stream_kind=0, stream_block=blk, st
         for cap, blk in ((2048, 256), (4096, 256), (4096, 512))]
 arms += [("x-window (local) cap=2048", dict(stream_kind=5, local_nt=1, stream_xcd=0), "local2048", sp.CSR_STREAM),
          ("x-window (local) cap=1024", dict(stream_kind=5, local_nt=1, stream_xcd=0), "local1024", sp.CSR_STREAM),
+         ("x-window (local) cap=3072", dict(stream_kind=5, local_nt=1, stream_xcd=0), "local3072", sp.CSR_STREAM),
+         ("x-window (local) cap=3072 nt=0", dict(stream_kind=5, local_nt=0, stream_xcd=0), "local3072", sp.CSR_STREAM),
          ("x-window (local) cap=2048 nt=0", dict(stream_kind=5, local_nt=0, stream_xcd=0), "local2048", sp.CSR_STREAM),
          ("x-window (local) cap=1024 nt=0", dict(stream_kind=5, local_nt=0, stream_xcd=0), "local1024", sp.CSR_STREAM),
          ("x-window (local) cap=2048 xcd=-1", dict(stream_kind=5, local_nt=1, stream_xcd=-1), "local2048", sp.CSR_STREAM),
