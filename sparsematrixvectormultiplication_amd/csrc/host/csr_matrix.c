@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "coo_group.h"
 #include "utility.h"
 
 void init_csr_matrix(CSRMatrix *mat) {
@@ -118,24 +119,21 @@ int convert_in_csr(const PreMatrix *pre, CSRMatrix *csr, const char *matrix_name
     csr->row_ptr = (int *)calloc(M + 1, sizeof(int));
     csr->col_idx = (int *)malloc((nz ? nz : 1) * sizeof(int));
     csr->values = (double *)malloc((nz ? nz : 1) * sizeof(double));
-    int *cursor = (int *)malloc((M ? M : 1) * sizeof(int));
-    if (!csr->row_ptr || !csr->col_idx || !csr->values || !cursor) {
+    if (!csr->row_ptr || !csr->col_idx || !csr->values) {
         printf("Errore di allocazione memoria nella conversione CSR\n");
-        free(cursor);
         free_csr_matrix(csr);
         return -1;
     }
 
-    /* histogram -> exclusive scan -> scatter in file order */
-    for (size_t e = 0; e < nz; ++e) csr->row_ptr[pre->I[e] + 1]++;
-    for (size_t r = 0; r < M; ++r) csr->row_ptr[r + 1] += csr->row_ptr[r];
-    memcpy(cursor, csr->row_ptr, M * sizeof(int));
-    for (size_t e = 0; e < nz; ++e) {
-        const int dst = cursor[pre->I[e]]++;
-        csr->col_idx[dst] = pre->J[e];
-        csr->values[dst] = pre->val[e];
+    /* histogram -> exclusive scan -> scatter in file order (all threads: coo_group.c); like the
+     * reference, indices are trusted here (read_matrix_market has checked them) */
+    int bad_r = 0, bad_c = 0;
+    if (coo_group_by_row(pre->M, -1, nz, pre->I, pre->J, pre->val, csr->row_ptr, csr->col_idx, csr->values,
+                         &bad_r, &bad_c) != 0) {
+        printf("Errore di allocazione memoria nella conversione CSR\n");
+        free_csr_matrix(csr);
+        return -1;
     }
-    free(cursor);
 
     /* ascending columns inside each row */
     int longest = 0;

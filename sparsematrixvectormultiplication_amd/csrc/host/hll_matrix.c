@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "coo_group.h"
 #include "utility.h"
 
 void init_hll_matrix(HLLMatrix *hll) {
@@ -99,38 +100,33 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
     const size_t nz = (size_t)pre->nz;
 
     int *row_off = (int *)calloc((size_t)M + 1, sizeof(int));
-    int *cursor = (int *)malloc(((size_t)M ? (size_t)M : 1) * sizeof(int));
     int *cols = (int *)malloc((nz ? nz : 1) * sizeof(int));
     double *vals = (double *)malloc((nz ? nz : 1) * sizeof(double));
     hll->blocks = (ELLPACKBlock *)calloc((size_t)(num_blocks ? num_blocks : 1), sizeof(ELLPACKBlock));
     hll->num_blocks = num_blocks;
     int *tc = NULL;
     double *tv = NULL;
-    if (!row_off || !cursor || !cols || !vals || !hll->blocks) {
+    if (!row_off || !cols || !vals || !hll->blocks) {
         printf("Errore di allocazione memoria per i blocchi HLL\n");
         goto fail;
     }
 
-    /* bucket the entries by row, keeping file order inside a row */
-    for (size_t e = 0; e < nz; ++e) {
-        const int r = pre->I[e], c = pre->J[e];
-        if (r < 0 || r >= M || c < 0 || c >= pre->N) {
-            printf("ERRORE: Indice non valido: riga=%d, colonna=%d\n", r, c);
+    /* bucket the entries by row, keeping file order inside a row (all threads: coo_group.c) */
+    {
+        int bad_r = 0, bad_c = 0;
+        const int g = coo_group_by_row(M, pre->N, nz, pre->I, pre->J, pre->val, row_off, cols, vals, &bad_r, &bad_c);
+        if (g == -2) {
+            printf("ERRORE: Indice non valido: riga=%d, colonna=%d\n", bad_r, bad_c);
             goto fail;
         }
-        row_off[r + 1]++;
+        if (g != 0) {
+            printf("Errore di allocazione memoria per i blocchi HLL\n");
+            goto fail;
+        }
     }
     int longest = 0;
-    for (int r = 0; r < M; ++r) {
-        if (row_off[r + 1] > longest) longest = row_off[r + 1];
-        row_off[r + 1] += row_off[r];
-    }
-    memcpy(cursor, row_off, (size_t)M * sizeof(int));
-    for (size_t e = 0; e < nz; ++e) {
-        const int dst = cursor[pre->I[e]]++;
-        cols[dst] = pre->J[e];
-        vals[dst] = pre->val[e];
-    }
+    for (int r = 0; r < M; ++r)
+        if (row_off[r + 1] - row_off[r] > longest) longest = row_off[r + 1] - row_off[r];
     /* rows are independent: order them with all threads (per-thread merge scratch) */
     {
         int bad_alloc = 0;
@@ -203,7 +199,6 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
         goto fail;
     }
     free(row_off);
-    free(cursor);
     free(cols);
     free(vals);
     free(tc);
@@ -212,7 +207,6 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
 
 fail:
     free(row_off);
-    free(cursor);
     free(cols);
     free(vals);
     free(tc);

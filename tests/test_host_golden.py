@@ -121,3 +121,49 @@ def test_partition_hacks_follows_the_reference_hack_partitioner(name, parts):
     assert np.all(bounds[len(starts) + 1:] == H) if len(starts) else bounds[1] == H
     rows = sp.hack_bounds_to_rows(bounds, pre.M)
     assert rows[-1] == pre.M and np.all((rows % 32 == 0) | (rows == pre.M))
+
+
+def test_builders_on_the_parallel_grouping_path():
+    """Above 2 M entries the builders group the COO triplets by row with all threads
+    (coo_group.c, two-level counting sort).  File order inside a row must survive, because both
+    tie rules are defined on it: a shuffled COO with repeated (row, column) pairs must come out
+    as numpy's stable sort says -- HLL exactly (its tie rule is stable), CSR exactly on rows
+    without repeats and as the same multiset on rows with repeats (goldens pin the quicksort
+    tie order itself)."""
+    rng = np.random.default_rng(321)
+    M, N, nz = 60000, 50000, 2_600_000
+    I = rng.integers(0, M, nz).astype(np.int32)
+    I[rng.random(nz) < 0.02] = 7                        # one heavy row
+    J = rng.integers(0, N, nz).astype(np.int32)
+    dup = rng.random(nz) < 0.01                         # repeated (row, column) pairs
+    src = rng.integers(0, nz, int(dup.sum()))
+    I[dup], J[dup] = I[src], J[src]
+    V = rng.uniform(-1, 1, nz)
+    order = np.lexsort((J, I))                          # by row, then column, ties in file order
+    rp_want = np.concatenate([[0], np.cumsum(np.bincount(I, minlength=M))]).astype(np.int32)
+    pre = sp.PreMatrix.from_arrays(M, N, I, J, V)
+    csr = sp.convert_in_csr(pre)
+    np.testing.assert_array_equal(csr.row_ptr, rp_want)
+    np.testing.assert_array_equal(csr.col_idx, J[order])            # columns: ties are equal anyway
+    want_v = V[order]
+    same = csr.values == want_v
+    # positions that differ must lie inside runs of one repeated column of one row
+    keys = I[order].astype(np.int64) * N + J[order]
+    run_start = np.concatenate([[True], keys[1:] != keys[:-1]])
+    run_id = np.cumsum(run_start) - 1
+    run_len = np.bincount(run_id)
+    assert np.all(run_len[run_id[~same]] > 1)
+    np.testing.assert_array_equal(np.sort(csr.values[~same]), np.sort(want_v[~same]))
+    hll = sp.convert_to_hll(pre)
+    for b in (0, 3, hll.num_blocks // 2, hll.num_blocks - 1):
+        rows, maxnz, JA, AS = hll.block(b)
+        for i in range(rows):
+            r = 32 * b + i
+            n = rp_want[r + 1] - rp_want[r]
+            seg = slice(rp_want[r], rp_want[r + 1])
+            np.testing.assert_array_equal(JA[i * maxnz:i * maxnz + n], J[order][seg])
+            assert AS[i * maxnz:i * maxnz + n].tobytes() == V[order][seg].tobytes()
+    # an index outside the matrix is still reported by the HLL builder
+    I[nz // 2] = M + 3
+    with pytest.raises(ValueError):
+        sp.convert_to_hll(sp.PreMatrix.from_arrays(M, N, I, J, V))
