@@ -11,11 +11,14 @@
  * The builder goes COO -> (row-bucketed, column-ordered pairs) -> hacks with
  * three flat scratch arrays, instead of the reference's one malloc per row.
  */
+#define _POSIX_C_SOURCE 200809L
 #include "hll_matrix.h"
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <time.h>
 
 #include "coo_group.h"
 #include "utility.h"
@@ -84,7 +87,15 @@ static void order_pairs_stable(int *col, double *val, int n, int *tc, double *tv
     }
 }
 
+static double hll_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
+    const int verbose = getenv("SPMV_VERBOSE") != NULL;
+    const double t_start = hll_now();
     if (!hll) {
         printf("Errore: Parametri non validi\n");
         return -1;
@@ -127,6 +138,7 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
     int longest = 0;
     for (int r = 0; r < M; ++r)
         if (row_off[r + 1] - row_off[r] > longest) longest = row_off[r + 1] - row_off[r];
+    const double t_grouped = hll_now();
     /* rows are independent: order them with all threads (per-thread merge scratch) */
     {
         int bad_alloc = 0;
@@ -153,6 +165,7 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
         }
     }
 
+    const double t_ordered = hll_now();
     /* one ELLPACK slab per hack, row-major, padded; hacks are independent */
     int hack_failed = 0;
 #pragma omp parallel for schedule(dynamic, 256)
@@ -198,6 +211,9 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
         printf("ERRORE: Allocazione fallita per un blocco HLL\n");
         goto fail;
     }
+    if (verbose)
+        printf("convert_to_hll: group by row %.3f s, order rows %.3f s, fill hacks %.3f s\n", t_grouped - t_start,
+               t_ordered - t_grouped, hll_now() - t_ordered);
     free(row_off);
     free(cols);
     free(vals);
