@@ -105,6 +105,8 @@ int spmv_hip_flush_cache(size_t bytes);
  *     "stream_cap"    0 (auto) | 1024 | 2048 | 3072 | 4096 | 8192 entries staged per workgroup of the gather stream
  *                     kernel; a value other than the x-window stage skips the x-window plan
  *     "stream_local"  1 | 0   build the x-window plan (16-bit local columns + line lists) when the matrix allows
+ *     "plan_on_device" 1 | 0  build that plan with the device kernels where they apply (every block within the
+ *                     line limit), else / otherwise on the host
  *     "local_cap"     0 (auto = 2048) | 1024 | 2048 | 3072   stage of the x-window kernels (3072: +0.5..3 % on the
  *                     nlpkkt-like matrix depending on the box, -8 % on the cant-like one)
  *   read at launch

@@ -4,6 +4,8 @@
 // :285-317, :682-685).
 #include "spmv_internal.hpp"
 
+#include "plan_kernels.hpp"
+
 // ----------------------------------------------------------- CSR: upload
 namespace {
 
@@ -115,6 +117,85 @@ bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, 
     return true;
 }
 
+// The x-window plan of the blocks `desc` (cut by entries and rows only) built on the device from the
+// uploaded column indices (plan_kernels.hpp).  1: the handle carries the plan; 0: some block lists
+// more than kLocalLinesMax lines, the host builder (which may cut blocks by lines or split rows)
+// has to decide; -1: HIP error.
+template <int SHIFT>
+int csr_plan_on_device(spmv_csr_dev *m, const std::vector<int4> &desc, long long nz) {
+    const int W = (int)desc.size();
+    if (W == 0) return 0;
+    std::vector<long long> seg_begin((size_t)W);
+    std::vector<int> seg_len((size_t)W);
+    for (int w = 0; w < W; ++w) {
+        seg_begin[w] = desc[w].y;
+        seg_len[w] = desc[w].w - desc[w].y;
+        if (seg_len[w] > kPlanCap) return 0;
+    }
+    long long *d_begin = nullptr;
+    int *d_len = nullptr, *d_n = nullptr, *d_off = nullptr;
+    int result = -1;
+    do {
+        if (upload_array(&d_begin, seg_begin.data(), seg_begin.size(), 0)) break;
+        if (upload_array(&d_len, seg_len.data(), seg_len.size(), 0)) break;
+        hipError_t e = hipMalloc((void **)&d_n, (size_t)W * sizeof(int));
+        if (e != hipSuccess) { fail("csr plan: hipMalloc failed: %s", hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL((plan_count<SHIFT>), dim3(W), dim3(kBlock), 0, g_stream, W, d_begin, d_len, m->col, d_n);
+        std::vector<int> nl((size_t)W);
+        e = hipMemcpyAsync(nl.data(), d_n, (size_t)W * sizeof(int), hipMemcpyDeviceToHost, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        if (e != hipSuccess) { fail("csr plan: count pass failed: %s", hipGetErrorString(e)); break; }
+        std::vector<int> line_off((size_t)W);
+        std::vector<int2> ldesc((size_t)W);
+        long long total = 0;
+        int widest = 0;
+        bool fits = true;
+        for (int w = 0; w < W && fits; ++w) {
+            const int n = std::max(nl[w], 1);  // a block of empty rows still stages one line
+            fits = nl[w] <= kLocalLinesMax && total + n < (1LL << 31);
+            line_off[w] = (int)total;
+            ldesc[w] = int2{(int)total, n};
+            total += n;
+            widest = std::max(widest, n);
+        }
+        if (!fits) { result = 0; break; }
+        if (upload_array(&d_off, line_off.data(), line_off.size(), 0)) break;
+        e = hipMalloc((void **)&m->lines, ((size_t)total + kLocalLinesMax) * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&m->lcol, ((size_t)nz + kPad) * sizeof(unsigned short));
+        if (e == hipSuccess) e = hipMemsetAsync(m->lines, 0, ((size_t)total + kLocalLinesMax) * sizeof(int), g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(m->lcol, 0, ((size_t)nz + kPad) * sizeof(unsigned short), g_stream);
+        if (e != hipSuccess) { fail("csr plan: allocation failed: %s", hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL((plan_fill<SHIFT>), dim3(W), dim3(kBlock), 0, g_stream, W, d_begin, d_len, m->col, d_off,
+                           m->lines, m->lcol);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        if (e != hipSuccess) { fail("csr plan: fill pass failed: %s", hipGetErrorString(e)); break; }
+        if (upload_array(&m->ldesc4, desc.data(), desc.size(), 1)) break;
+        if (upload_array(&m->ldesc, ldesc.data(), ldesc.size(), 1)) break;
+        m->local_blocks = W;
+        m->local_lines = total;
+        m->local_stage_lines = std::max(kLocalLineQuantum,
+                                        (widest + kLocalLineQuantum - 1) / kLocalLineQuantum * kLocalLineQuantum);
+        result = 1;
+    } while (0);
+    (void)hipFree(d_begin);
+    (void)hipFree(d_len);
+    (void)hipFree(d_n);
+    (void)hipFree(d_off);
+    if (result != 1) {
+        (void)hipFree(m->lines);
+        (void)hipFree(m->lcol);
+        (void)hipFree(m->ldesc4);
+        (void)hipFree(m->ldesc);
+        m->lines = nullptr;
+        m->lcol = nullptr;
+        m->ldesc4 = nullptr;
+        m->ldesc = nullptr;
+        m->local_blocks = 0;
+    }
+    return result;
+}
+
 template <typename T>
 int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const T *values, int row0,
                     int row1, spmv_csr_dev **out) {
@@ -166,10 +247,29 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     constexpr int line_shift = sizeof(T) == 8 ? 4 : 5;  // 128-byte lines
     // (1024-entry blocks were tried for small matrices: cant-like 13.2 us against 11.7 us at 2048)
     const int lcap = g_local_cap ? g_local_cap : 2048;
+    bool on_device = false;
     if (g_stream_local && nz > 0 && (g_stream_cap == 0 || g_stream_cap == lcap)) {
         csr_build_blocks(Ml, rp.data(), lcap, kStreamRowsCap, desc, pieces, long_rows);
-        have_local = csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, lcap, kStreamRowsCap, line_shift,
+        // on the device when no block lists more than 256 lines (the common case for matrices that get
+        // a plan at all: then the line limit would not have moved a block boundary on the host either);
+        // otherwise the host builder decides (line-limited blocks, split rows, or no plan)
+        int dev = 0;
+        if (g_plan_on_device && lcap == kPlanCap) {
+            if (upload_array(&m->col, col_idx + e0, (size_t)nz, kPad)) {
+                spmv_hip_csr_free(m);
+                return -1;
+            }
+            dev = csr_plan_on_device<line_shift>(m, desc, nz);
+            if (dev < 0) {
+                spmv_hip_csr_free(m);
+                return -1;
+            }
+        }
+        on_device = dev == 1;
+        have_local = on_device ||
+                     csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, lcap, kStreamRowsCap, line_shift,
                                      kLocalLinesMax, desc, local);
+        if (on_device) local.split.assign((size_t)Ml, 0);
     }
     // else: larger stages amortise per-workgroup latency on big matrices; small ones need
     // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
@@ -187,7 +287,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
 
     int rc = 0;
     rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), (size_t)kRingRows + 64);
-    if (!rc && have_local) {
+    if (!rc && have_local && !on_device) {
         rc |= upload_array(&m->ldesc4, local.desc.data(), local.desc.size(), 1);
         if (!rc) rc |= upload_array(&m->ldesc, local.ldesc.data(), local.ldesc.size(), 1);
         if (!rc) rc |= upload_array(&m->lines, local.lines.data(), local.lines.size(), 0);
@@ -198,7 +298,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
             m->local_lines = (long long)local.lines.size() - kLocalLinesMax;
         }
     }
-    if (!rc) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
+    if (!rc && !m->col) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
     if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
@@ -224,7 +324,8 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
                       long_rows.size() * 16 + pieces.size() * 16 + (size_t)num_partial * sizeof(T) +
                       ((size_t)N + (size_t)M) * sizeof(T);
     if (have_local)
-        m->device_bytes += local.desc.size() * 24 + local.lines.size() * 4 + local.lcol.size() * 2;
+        m->device_bytes += (size_t)m->local_blocks * 24 + ((size_t)m->local_lines + kLocalLinesMax) * 4 +
+                           ((size_t)nz + kPad) * 2;
 
     // lanes per row for the SUBWAVE kernel: about half the mean row length,
     // rounded to a power of two, so that a typical row takes 1-2 passes

@@ -37,6 +37,7 @@ int g_stream_xcd = 0;
 int g_gather_mode = 0;
 int g_local_cap = 0;
 int g_stream_local = 1;
+int g_plan_on_device = 1;
 int g_stream_kind = -1;
 int g_pipe_wgs_per_cu = 5;
 int g_num_cus = 256;
@@ -148,6 +149,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         if (value != 0 && value != 1024 && value != 2048 && value != 3072)
             return fail("set_tuning: local_cap must be 0, 1024, 2048 or 3072");
         g_local_cap = value;  // takes effect at the next upload
+    } else if (!strcmp(key, "plan_on_device")) {
+        g_plan_on_device = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "stream_local")) {
         g_stream_local = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "pipe_wgs_per_cu")) {

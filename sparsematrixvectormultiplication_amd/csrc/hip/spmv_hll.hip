@@ -3,6 +3,8 @@
 // allocations and launches of /root/reference/main_cuda.cu:369-455, :545-568, :613-637, :731-744.
 #include "spmv_internal.hpp"
 
+#include "plan_kernels.hpp"
+
 namespace {
 
 // first pass of the device builder (see hll_fill_from_csr in hll_kernels.hpp): per-hack maximum row length
@@ -318,6 +320,95 @@ extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, 
     return spmv_hip_hll_upload_part(hll, total_rows, N, 0, hll->num_blocks, out);
 }
 
+namespace {
+
+// x-window plan of a device-resident slab, built by plan_count / plan_fill.  Returns 1 when the handle
+// now carries the plan, 0 when some window lists more than kLocalLinesMax lines (caller falls back to
+// the host builder), -1 on a HIP error.
+int hll_plan_on_device(spmv_hll_dev *m, int total_rows, const std::vector<long long> &off, const std::vector<int> &mz) {
+    const int H = (int)mz.size();
+    std::vector<int4> win;
+    hll_build_blocks(total_rows, H, off.data(), mz.data(), kPlanCap, win);
+    const int W = (int)win.size();
+    if (W == 0) return 0;
+    auto start_of = [&](int r) { return off[r / kHack] + (long long)(r % kHack) * mz[r / kHack]; };
+    std::vector<long long> seg_begin((size_t)W);
+    std::vector<int> seg_len((size_t)W), count((size_t)W);
+    for (int w = 0; w < W; ++w) {
+        const int r0 = win[w].x, r1 = r0 + win[w].y - 1;
+        const long long s0 = start_of(r0), end = start_of(r1) + mz[r1 / kHack];
+        if (end - (s0 & ~1LL) > kPlanCap) return 0;  // a row that alone exceeds the stage: no plan
+        seg_begin[w] = s0;
+        seg_len[w] = (int)(end - s0);
+        count[w] = (int)(end - (s0 & ~1LL));
+    }
+    long long *d_begin = nullptr;
+    int *d_len = nullptr, *d_n = nullptr, *d_off = nullptr;
+    int result = -1;
+    do {
+        if (upload_array(&d_begin, seg_begin.data(), seg_begin.size(), 0)) break;
+        if (upload_array(&d_len, seg_len.data(), seg_len.size(), 0)) break;
+        hipError_t e = hipMalloc((void **)&d_n, (size_t)W * sizeof(int));
+        if (e != hipSuccess) { fail("hll plan: hipMalloc failed: %s", hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL((plan_count<4>), dim3(W), dim3(kBlock), 0, g_stream, W, d_begin, d_len, m->JA, d_n);
+        std::vector<int> nl((size_t)W);
+        e = hipMemcpyAsync(nl.data(), d_n, (size_t)W * sizeof(int), hipMemcpyDeviceToHost, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        if (e != hipSuccess) { fail("hll plan: count pass failed: %s", hipGetErrorString(e)); break; }
+        std::vector<int> line_off((size_t)W);
+        std::vector<int4> ldesc((size_t)W);
+        long long total = 0;
+        int widest = 0;
+        bool fits = true;
+        for (int w = 0; w < W && fits; ++w) {
+            const int n = std::max(nl[w], 1);  // a window of empty rows still stages one line
+            fits = nl[w] <= kLocalLinesMax && total + n < (1LL << 31);
+            line_off[w] = (int)total;
+            ldesc[w] = int4{(int)total, n, count[w], 0};
+            total += n;
+            widest = std::max(widest, n);
+        }
+        if (!fits) { result = 0; break; }
+        if (upload_array(&d_off, line_off.data(), line_off.size(), 0)) break;
+        const size_t S = (size_t)off[H];
+        e = hipMalloc((void **)&m->lines, ((size_t)total + kLocalLinesMax) * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&m->lja, (S + kPad) * sizeof(unsigned short));
+        if (e == hipSuccess) e = hipMemsetAsync(m->lines, 0, ((size_t)total + kLocalLinesMax) * sizeof(int), g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(m->lja, 0, (S + kPad) * sizeof(unsigned short), g_stream);
+        if (e != hipSuccess) { fail("hll plan: allocation failed: %s", hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL((plan_fill<4>), dim3(W), dim3(kBlock), 0, g_stream, W, d_begin, d_len, m->JA, d_off,
+                           m->lines, m->lja);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        if (e != hipSuccess) { fail("hll plan: fill pass failed: %s", hipGetErrorString(e)); break; }
+        if (upload_array(&m->ldesc4, win.data(), win.size(), 1)) break;
+        if (upload_array(&m->ldesc, ldesc.data(), ldesc.size(), 1)) break;
+        m->local_blocks = W;
+        m->local_lines = total;
+        m->local_stage_lines = std::max(kLocalLineQuantum,
+                                        (widest + kLocalLineQuantum - 1) / kLocalLineQuantum * kLocalLineQuantum);
+        result = 1;
+    } while (0);
+    (void)hipFree(d_begin);
+    (void)hipFree(d_len);
+    (void)hipFree(d_n);
+    (void)hipFree(d_off);
+    if (result != 1) {  // leave no half-built plan behind
+        (void)hipFree(m->lines);
+        (void)hipFree(m->lja);
+        (void)hipFree(m->ldesc4);
+        (void)hipFree(m->ldesc);
+        m->lines = nullptr;
+        m->lja = nullptr;
+        m->ldesc4 = nullptr;
+        m->ldesc = nullptr;
+        m->local_blocks = 0;
+    }
+    return result;
+}
+
+}  // namespace
+
 // HLL built on the device from a resident CSR matrix (whole matrix, fp64).
 extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out) {
     if (need_device()) return -1;
@@ -361,15 +452,25 @@ extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out
             if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
             if (e != hipSuccess) { rc = fail("hll_from_csr: fill failed: %s", hipGetErrorString(e)); break; }
         }
-        // the x-window plan is built on the host from the finished JA (one D2H copy of 4 bytes per slot)
+        // the x-window plan: on the device when every 2048-slot window lists at most 256 lines (then the
+        // line limit would not have moved any window boundary on the host either); otherwise the host
+        // builder decides (line-limited windows or no plan), from one D2H copy of JA
+        int planned = 0;
+        if (g_stream_local && g_plan_on_device && S > 0) {
+            planned = hll_plan_on_device(m, M, off, mz);
+            if (planned < 0) { rc = -1; break; }
+        }
         std::vector<int> ja_host;
-        if (g_stream_local && S > 0) {
+        if (g_stream_local && S > 0 && !planned) {
             ja_host.resize((size_t)S);
             e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
         }
         rc = hll_finish_handle(m, M, N, off, mz, true_slots, false, ja_host.empty() ? nullptr : ja_host.data(),
                                csr->M_total, csr->row0);
+        if (!rc && planned)
+            m->device_bytes += (size_t)m->local_blocks * 32 + ((size_t)m->local_lines + kLocalLinesMax) * 4 +
+                               ((size_t)S + kPad) * 2;
     } while (0);
     if (rc) {
         spmv_hip_hll_free(m);

@@ -36,6 +36,7 @@ extern int g_stream_xcd;      // blocks per XCD run (xcd_chunked); 0 = default, 
 extern int g_gather_mode;     // all-gatherv: 0 = one ncclBroadcast per owner in a group, 1 = padded ncclAllGather + scatter
 extern int g_local_cap;       // stage of the x-window plan: 0 = auto, 1024 or 2048
 extern int g_stream_local;    // build the x-window plan at upload when it pays
+extern int g_plan_on_device;  // ... with the device kernels where they apply (0: always on the host)
 extern int g_stream_kind;     // -1 = auto (x-window kernel when the matrix has a plan, else csr_stream), 5 = x-window,
                               // 0 = csr_stream, 1 = row walk, 2 = pipe, 3 = persistent walk, 4 = ring, 10..17 = probes
 extern int g_pipe_wgs_per_cu; // resident workgroups per CU the persistent grids are sized for

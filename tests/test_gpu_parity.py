@@ -784,3 +784,39 @@ def test_power_iteration_matches_the_oracle_loop(gpu, oracle):
     with sp.CsrDevice(50, 60, rp2, c2, v2) as rect:
         with pytest.raises(RuntimeError, match="square"):
             rect.power_iterate(2)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_plan_built_on_the_device_equals_the_host_plan(gpu, oracle, dtype):
+    """plan_count / plan_fill (LDS sort + unique per block) against csr_build_local / hll_build_local: the
+    same blocks, the same number of listed lines, the same bits out of the kernels; a matrix whose
+    blocks exceed the line limit falls back to the host builder either way."""
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    from _util import banded_csr
+    rng = np.random.default_rng(77)
+    M, N = 9001, 9300
+    for mean, band, empty in ((4, 50, 0.3), (30, 180, 0.0), (120, 900, 0.0)):
+        row_ptr, col, val = banded_csr(rng, M, N, mean, band, empty, dtype=dtype)
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        got = {}
+        try:
+            for where in (1, 0):
+                set_tuning("plan_on_device", where)
+                with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
+                    info = dev.info()
+                    y = dev.spmv(x, sp.CSR_STREAM)
+                    entry = [info["local_blocks"], info["local_lines"], info["local_stage_lines"], y.tobytes()]
+                    if dtype == np.float64:
+                        with sp.HllDevice.from_csr_device(dev) as h:
+                            hi = h.info()
+                            entry += [hi["local_blocks"], hi["local_stage_lines"], h.spmv(x, sp.HLL_LDS).tobytes()]
+                    got[where] = entry
+        finally:
+            set_tuning("plan_on_device", 1)
+        assert got[1][0] > 0, "banded matrix should get a plan"
+        assert got[1] == got[0], f"device-built plan differs from the host-built one (mean={mean})"
+    # blocks beyond the line limit: the device pass reports it, the host builder takes over (and cuts by lines)
+    row_ptr, col, val = banded_csr(rng, 3000, 40000, 30, 1500)
+    x = rng.uniform(-1, 1, 40000)
+    with sp.CsrDevice(3000, 40000, row_ptr, col, val) as dev:
+        assert_parity(dev.spmv(x, sp.CSR_STREAM), oracle.csr_serial(row_ptr, col, val, x), row_ptr, col, val, x)
