@@ -141,6 +141,16 @@ int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx
  * stats[6] (optional): gather blocks, x-window blocks (0 = no plan), listed lines, widest block's lines, long
  * rows, rows handed to the split-row kernels because they alone touch too many lines. */
 int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, int *stats);
+/* COO triplets (0-based, any order) -> a CSR handle, built ON THE DEVICE (upload of the
+ * triplets, one stable radix sort by (row, column), row pointers and the x-window plan by kernels).  Same
+ * matrix as convert_in_csr + spmv_hip_csr_upload_matrix; entries that repeat one (row, column) keep file
+ * order here (the reference's quicksort leaves them in its own order), which only reorders equal-column
+ * terms of a row's sum. */
+int spmv_hip_csr_from_coo(int M, int N, long long nz, const int *I, const int *J, const double *val,
+                          spmv_csr_dev **out);
+/* the handle's CSR arrays back to the host: row_ptr[M_local + 1] rebased to 0, col[nz], val[nz] (handle's
+ * dtype); any pointer may be NULL */
+int spmv_hip_csr_download(const spmv_csr_dev *m, int *row_ptr, int *col, void *val);
 /* convenience over the kept struct */
 int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **out);
 void spmv_hip_csr_free(spmv_csr_dev *m);

@@ -183,6 +183,9 @@ _PROTOTYPES = {
                                                C.c_void_p]),
     "spmv_hip_comm_autotune": (C.c_int, [C.c_void_p, c_int_p, C.c_int, C.c_int, c_int_p, c_float_p]),
     "spmv_hip_hll_plan_check": (C.c_int, [C.POINTER(HLLMatrix), C.c_int, C.c_int, c_int_p]),
+    "spmv_hip_csr_from_coo": (C.c_int, [C.c_int, C.c_int, C.c_longlong, c_int_p, c_int_p, c_double_p,
+                                        C.POINTER(C.c_void_p)]),
+    "spmv_hip_csr_download": (C.c_int, [C.c_void_p, c_int_p, c_int_p, C.c_void_p]),
     "spmv_hip_csr_plan_check": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p]),
     "spmv_hip_csr_power_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, c_double_p,
                                              c_float_p]),

@@ -198,7 +198,9 @@ int csr_plan_on_device(spmv_csr_dev *m, const std::vector<int4> &desc, long long
 
 template <typename T>
 int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const T *values, int row0,
-                    int row1, spmv_csr_dev **out) {
+                    int row1, spmv_csr_dev **out, int *adopt_col = nullptr, T *adopt_val = nullptr) {
+    // adopt_col / adopt_val: device arrays of row_ptr[row1] - row_ptr[row0] (+ kPad zeroed) entries that the
+    // handle takes over instead of uploading col_idx / values (which are then NULL); columns already checked
     if (need_device()) return -1;
     if (!out) return fail("csr_upload: out is NULL");
     *out = nullptr;
@@ -208,22 +210,30 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     const int e0 = row_ptr[row0], e1 = row_ptr[row1];
     const long long nz = (long long)e1 - e0;
     if (nz < 0) return fail("csr_upload: row_ptr is not monotone");
-    if (nz > 0 && (!col_idx || !values)) return fail("csr_upload: col_idx / values are NULL");
+    if (nz > 0 && !adopt_col && (!col_idx || !values)) return fail("csr_upload: col_idx / values are NULL");
     if ((unsigned long long)N * sizeof(T) >= (1ull << 32))
         return fail("csr_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
     // a column index outside [0, N) would make the kernels gather out of bounds
-    for (int e = e0; e < e1; ++e)
+    for (int e = e0; e < e1 && col_idx; ++e)
         if ((unsigned)col_idx[e] >= (unsigned)N)
             return fail("csr_upload: column index %d at entry %d is outside [0, %d)", col_idx[e], e, N);
 
     spmv_csr_dev *m = new (std::nothrow) spmv_csr_dev();
     if (!m) return fail("csr_upload: out of host memory");
+    // on failure adopted arrays go back to the caller untouched
+    auto drop = [&](spmv_csr_dev *h) {
+        if (adopt_col) h->col = nullptr;
+        if (adopt_val) h->val = nullptr;
+        spmv_hip_csr_free(h);
+    };
     m->value_bytes = (int)sizeof(T);
     m->M_local = Ml;
     m->M_total = M;
     m->N = N;
     m->row0 = row0;
     m->nz = nz;
+    m->col = adopt_col;
+    m->val = adopt_val;
 
     std::vector<int> rp((size_t)Ml + 1);
     int max_row = 0;
@@ -255,20 +265,28 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
         // otherwise the host builder decides (line-limited blocks, split rows, or no plan)
         int dev = 0;
         if (g_plan_on_device && lcap == kPlanCap) {
-            if (upload_array(&m->col, col_idx + e0, (size_t)nz, kPad)) {
-                spmv_hip_csr_free(m);
+            if (!m->col && upload_array(&m->col, col_idx + e0, (size_t)nz, kPad)) {
+                drop(m);
                 return -1;
             }
             dev = csr_plan_on_device<line_shift>(m, desc, nz);
             if (dev < 0) {
-                spmv_hip_csr_free(m);
+                drop(m);
                 return -1;
             }
         }
         on_device = dev == 1;
+        std::vector<int> col_back;  // adopted arrays live on the device only: the host builder needs a copy
+        if (!on_device && !col_idx) {
+            col_back.resize((size_t)nz);
+            if (hipMemcpy(col_back.data(), m->col, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+                drop(m);
+                return fail("csr_upload: copying the columns back for the host plan failed");
+            }
+        }
         have_local = on_device ||
-                     csr_build_local(Ml, N, rp.data(), col_idx + e0, nz, lcap, kStreamRowsCap, line_shift,
-                                     kLocalLinesMax, desc, local);
+                     csr_build_local(Ml, N, rp.data(), col_idx ? col_idx + e0 : col_back.data(), nz, lcap,
+                                     kStreamRowsCap, line_shift, kLocalLinesMax, desc, local);
         if (on_device) local.split.assign((size_t)Ml, 0);
     }
     // else: larger stages amortise per-workgroup latency on big matrices; small ones need
@@ -299,7 +317,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
         }
     }
     if (!rc && !m->col) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
-    if (!rc) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
+    if (!rc && !m->val) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
     if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
     if (!rc && num_partial) rc |= upload_array(&m->pieces, pieces.data(), pieces.size(), 0);
@@ -317,7 +335,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
         if (e != hipSuccess) rc = fail("hipMalloc(x/y) failed: %s", hipGetErrorString(e));
     }
     if (rc) {
-        spmv_hip_csr_free(m);
+        drop(m);
         return -1;
     }
     m->device_bytes = rp.size() * 4 + ((size_t)nz + kPad) * (4 + sizeof(T)) + desc.size() * 16 +
@@ -431,6 +449,11 @@ extern "C" int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const i
         stats[5] = split_rows;
     }
     return 0;
+}
+
+// a whole fp64 matrix whose col / val already sit on the device (spmv_coo.hip)
+int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_val, spmv_csr_dev **out) {
+    return csr_upload_impl<double>(M, N, row_ptr_host, nullptr, nullptr, 0, M, out, d_col, d_val);
 }
 
 extern "C" int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,

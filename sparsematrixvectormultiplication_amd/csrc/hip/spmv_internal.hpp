@@ -157,6 +157,10 @@ struct LocalPlan {
     int stage_lines = 0;
 };
 
+// spmv_csr.hip: a handle around device arrays that already hold the matrix (ownership passes to the handle
+// on success only); col / val carry kPad zeroed entries behind the last one
+int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_val, spmv_csr_dev **out);
+
 // launchers the timing / exchange code calls across translation units
 int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s);
 int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_full, hipStream_t s);

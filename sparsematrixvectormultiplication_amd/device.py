@@ -113,6 +113,30 @@ class CsrDevice(_Handle):
         self.M, self.N = int(M), int(N)
 
     @classmethod
+    def from_coo(cls, M, N, I, J, val):
+        """CSR built on the device from COO triplets (spmv_hip_csr_from_coo); fp64."""
+        I = np.ascontiguousarray(I, dtype=np.int32)
+        J = np.ascontiguousarray(J, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        self = cls.__new__(cls)
+        _Handle.__init__(self)
+        _check(nat.lib().spmv_hip_csr_from_coo(int(M), int(N), len(I), I.ctypes.data_as(nat.c_int_p),
+                                               J.ctypes.data_as(nat.c_int_p), val.ctypes.data_as(nat.c_double_p),
+                                               C.byref(self.h)), "spmv_hip_csr_from_coo")
+        self.M, self.N, self.dtype = int(M), int(N), np.float64
+        return self
+
+    def download(self):
+        """(row_ptr, col_idx, values) of the handle's rows, from the device."""
+        info = self.info()
+        rp = np.zeros(info["M_local"] + 1, dtype=np.int32)
+        col = np.zeros(max(info["nz"], 1), dtype=np.int32)
+        val = np.zeros(max(info["nz"], 1), dtype=self.dtype)
+        _check(nat.lib().spmv_hip_csr_download(self.h, rp.ctypes.data_as(nat.c_int_p), col.ctypes.data_as(nat.c_int_p),
+                                               val.ctypes.data_as(C.c_void_p)), "spmv_hip_csr_download")
+        return rp, col[:info["nz"]], val[:info["nz"]]
+
+    @classmethod
     def from_host(cls, csr: CsrHost, row0=0, row1=None):
         return cls(csr.M, csr.N, csr.row_ptr, csr.col_idx, csr.values, row0, row1)
 

@@ -820,3 +820,65 @@ def test_plan_built_on_the_device_equals_the_host_plan(gpu, oracle, dtype):
     x = rng.uniform(-1, 1, 40000)
     with sp.CsrDevice(3000, 40000, row_ptr, col, val) as dev:
         assert_parity(dev.spmv(x, sp.CSR_STREAM), oracle.csr_serial(row_ptr, col, val, x), row_ptr, col, val, x)
+
+
+# ------------------------------------------- CSR built on the device from COO (N1)
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_csr_from_coo_on_device_golden(gpu, name):
+    """spmv_hip_csr_from_coo against the host builder on the golden matrices: the same CSR arrays bit for
+    bit where no (row, column) repeats; with repeats the same row_ptr / columns and the same multiset of
+    values per run (the device sort is stable, the reference's quicksort is not); SpMV parity either way."""
+    g = load_golden(name)
+    pre = sp.read_matrix_market(golden_path(name))
+    csr = sp.convert_in_csr(pre)
+    with sp.CsrDevice.from_coo(pre.M, pre.N, pre.I, pre.J, pre.val) as dev:
+        rp, col, val = dev.download()
+        np.testing.assert_array_equal(rp, csr.row_ptr)
+        np.testing.assert_array_equal(col, csr.col_idx)
+        if name == "dup_entries":
+            np.testing.assert_array_equal(np.sort(val), np.sort(csr.values))
+        else:
+            assert val.tobytes() == csr.values.tobytes()
+        for x, key in ((np.ones(csr.N), "y_ones"), (g["x_rand"], "y_rand")):
+            for vname, variant in CSR_V:
+                assert_parity(dev.spmv(x, variant), g[key], csr.row_ptr, csr.col_idx, csr.values, x,
+                              what=f"{name}/from_coo/{vname}")
+
+
+def test_csr_from_coo_on_device_large_shuffled(gpu, oracle):
+    """3 M shuffled triplets with empty rows, a heavy row and rows longer than the stage: CSR arrays equal to
+    convert_in_csr's bit for bit, the handle gets its x-window plan, and the device-built HLL follows."""
+    from _util import banded_csr
+    rng = np.random.default_rng(99)
+    M, N = 70001, 70500
+    row_ptr, col, val = banded_csr(rng, M, N, 40, 300, 0.05)
+    rows = np.repeat(np.arange(M, dtype=np.int32), np.diff(row_ptr))
+    perm = rng.permutation(len(col))
+    I, J, V = rows[perm], col[perm], val[perm]
+    with sp.CsrDevice.from_coo(M, N, I, J, V) as dev:
+        rp, c2, v2 = dev.download()
+        np.testing.assert_array_equal(rp, row_ptr)
+        np.testing.assert_array_equal(c2, col)
+        assert v2.tobytes() == val.tobytes()
+        assert dev.info()["local_blocks"] > 0
+        x = rng.uniform(-1, 1, N)
+        y_ref = oracle.csr_serial(row_ptr, col, val, x)
+        assert_parity(dev.spmv(x), y_ref, row_ptr, col, val, x, what="from_coo large")
+        with sp.HllDevice.from_csr_device(dev) as h:
+            assert_parity(h.spmv(x), y_ref, row_ptr, col, val, x, what="from_coo -> hll")
+    # degenerate and bad inputs
+    with sp.CsrDevice.from_coo(5, 7, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)) as empty:
+        assert np.array_equal(empty.download()[0], np.zeros(6, np.int32))
+        assert np.array_equal(empty.spmv(np.ones(7)), np.zeros(5))
+    with pytest.raises(RuntimeError, match="outside"):
+        sp.CsrDevice.from_coo(5, 7, np.array([1, 5], np.int32), np.array([0, 0], np.int32), np.ones(2))
+    # scattered columns: no plan on the device, the host builder is asked (columns copied back) and refuses too
+    Is = rng.integers(0, 3000, 90000).astype(np.int32)
+    Js = rng.integers(0, 40000, 90000).astype(np.int32)
+    Vs = rng.uniform(-1, 1, 90000)
+    with sp.CsrDevice.from_coo(3000, 40000, Is, Js, Vs) as sc:
+        assert sc.info()["local_blocks"] == 0
+        ref = sp.convert_in_csr(sp.PreMatrix.from_arrays(3000, 40000, Is, Js, Vs))
+        x = rng.uniform(-1, 1, 40000)
+        assert_parity(sc.spmv(x), oracle.csr_serial(ref.row_ptr, ref.col_idx, ref.values, x), ref.row_ptr,
+                      ref.col_idx, ref.values, x, what="from_coo scattered")

@@ -27,3 +27,26 @@ for name, (M, row_ptr, col, val) in (("cant-like", synth.fem_like(synth.FEM_GRID
             print(f"{name:12s} HLL from resident CSR incl. plan: {time.perf_counter() - t:.3f} s", flush=True)
             h.close()
         d.close()
+
+# COO -> CSR: host builder + upload against the device builder (triplets shuffled, as from an unordered file)
+rng = np.random.default_rng(0)
+for name, (M, row_ptr, col, val) in (("nlpkkt-like", synth.kkt_like(synth.KKT_GRID, 1)),):
+    rows = np.repeat(np.arange(M, dtype=np.int32), np.diff(row_ptr))
+    for label, perm in (("row-sorted", None), ("shuffled", rng.permutation(len(col)))):
+        I, J, V = (rows, col, val) if perm is None else (rows[perm], col[perm], val[perm])
+        t = time.perf_counter()
+        csr = sp.convert_in_csr(sp.PreMatrix.from_arrays(M, M, I, J, V))
+        t1 = time.perf_counter()
+        d = sp.CsrDevice.from_host(csr)
+        sp.hip_sync()
+        t2 = time.perf_counter()
+        d.close()
+        best = 1e9
+        for _ in range(2):
+            t3 = time.perf_counter()
+            d = sp.CsrDevice.from_coo(M, M, I, J, V)
+            sp.hip_sync()
+            best = min(best, time.perf_counter() - t3)
+            d.close()
+        print(f"{name:12s} COO ({label}) -> device CSR: host convert_in_csr {t1 - t:.3f} s + upload {t2 - t1:.3f} s; "
+              f"spmv_hip_csr_from_coo {best:.3f} s", flush=True)
