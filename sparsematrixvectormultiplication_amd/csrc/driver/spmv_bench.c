@@ -78,6 +78,9 @@ static int run_gpu(int is_hll, void *dev, int variant, MediumPerformanceMetric s
 static int g_hll_on_device = 0;
 /* --cache: with --hll-on-device and no --oracle, CSR comes from "<file>.csrbin" when fresh */
 static int g_cache = 0;
+/* --csr-on-device: with --hll-on-device and no --oracle, the parsed triplets go straight to the GPU
+ * (spmv_hip_csr_from_coo): no convert_in_csr on the host */
+static int g_csr_on_device = 0;
 
 static int bench_matrix(const char *path, const char *name, const char *out_dir, int iters,
                         serial_csr_fn serial_csr, serial_hll_fn serial_hll) {
@@ -87,7 +90,14 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
     const int host_hll = !g_hll_on_device || serial_hll != NULL;
     memset(&hll, 0, sizeof hll);
     init_pre_matrix(&pre);
-    if (g_cache && !host_hll) {
+    const int device_csr = g_csr_on_device && !host_hll && serial_csr == NULL;
+    init_csr_matrix(&csr);
+    if (device_csr) {
+        if (process_matrix_file(path, &pre) != 0) return -1;
+        csr.M = pre.M; /* only the sizes are used below; the arrays stay on the device */
+        csr.N = pre.N;
+        csr.nz = pre.nz;
+    } else if (g_cache && !host_hll) {
         /* nothing downstream needs the COO triplets: take the built CSR from its sidecar */
         int hit = 0;
         if (load_csr_cached(path, &csr, &hit) != 0) return -1;
@@ -107,7 +117,9 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
 
     spmv_csr_dev *dcsr = NULL;
     spmv_hll_dev *dhll = NULL;
-    int rc = spmv_hip_csr_upload_matrix(&csr, &dcsr) || spmv_hip_csr_set_x(dcsr, x) ||
+    int rc = (device_csr ? spmv_hip_csr_from_coo(pre.M, pre.N, pre.nz, pre.I, pre.J, pre.val, &dcsr)
+                         : spmv_hip_csr_upload_matrix(&csr, &dcsr)) ||
+             spmv_hip_csr_set_x(dcsr, x) ||
              (g_hll_on_device ? spmv_hip_hll_from_csr(dcsr, &dhll) : spmv_hip_hll_upload(&hll, M, N, &dhll)) ||
              spmv_hip_hll_set_x(dhll, x);
     if (rc) {
@@ -208,10 +220,11 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--hll-on-device")) g_hll_on_device = 1;
         else if (!strcmp(argv[i], "--cache")) g_cache = 1;
+        else if (!strcmp(argv[i], "--csr-on-device")) g_csr_on_device = 1;
         else target = argv[i];
     }
     if (!target) {
-        fprintf(stderr, "usage: %s [--oracle liboracle_spmv.so] [--out dir] [--iters n] [--hll-on-device] [--cache] <file.mtx|dir>\n", argv[0]);
+        fprintf(stderr, "usage: %s [--oracle liboracle_spmv.so] [--out dir] [--iters n] [--hll-on-device] [--cache] [--csr-on-device] <file.mtx|dir>\n", argv[0]);
         return 2;
     }
     serial_csr_fn serial_csr = NULL;

@@ -42,6 +42,14 @@ def test_c_driver_runs_reference_protocol_on_golden_matrices(tmp_path, gpu):
     for r in csv.DictReader(open(out2 / "spmv_results_hip.csv")):
         for key in ("relative_error_row_hll", "relative_error_warp_hll", "relative_error_warp_shared_hll"):
             assert float(r[key]) < 1e-10, (r["matrix_name"], key, r[key])
+    # --csr-on-device --hll-on-device: nothing but the parser runs on the host; the reference value for the
+    # error columns is then the thread-per-row GPU kernel (no oracle in this mode), so compare the streams
+    out3 = tmp_path / "result_dev2"
+    proc = subprocess.run([DRIVER, "--out", str(out3), "--iters", "6", "--hll-on-device", "--csr-on-device", GOLDEN],
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    roof3 = list(csv.DictReader(open(out3 / "spmv_results_hip_roofline.csv")))
+    assert len(roof3) == len(rows) and all(float(r["rel_err_stream_csr"]) < 1e-10 for r in roof3)
 
 
 def test_c_driver_fails_loudly_without_a_gpu(tmp_path):
