@@ -80,6 +80,17 @@ for case in range(cases):
             with sp.HllDevice.from_csr_device(dev) as h:
                 stats["hll_plan"] += h.info()["local_blocks"] > 0
                 assert_parity(h.spmv(x, sp.HLL_AUTO), y_ref, row_ptr, col, val, x, what="HLL " + what)
+            keys = np.repeat(np.arange(M, dtype=np.int64), np.diff(row_ptr)) * N + col
+            if not unsorted and len(np.unique(keys)) == len(keys):   # no (row, column) pair repeats
+                # the same matrix built on the device from shuffled triplets: identical CSR arrays
+                rows_of = np.repeat(np.arange(M, dtype=np.int32), np.diff(row_ptr))
+                perm = rng.permutation(len(col))
+                with sp.CsrDevice.from_coo(M, N, rows_of[perm], col[perm], val[perm]) as built:
+                    rp_b, col_b, val_b = built.download()
+                    assert np.array_equal(rp_b, row_ptr) and np.array_equal(col_b, col) and \
+                        val_b.tobytes() == val.tobytes(), "from_coo " + what
+                    assert built.spmv(x, sp.CSR_AUTO).tobytes() == y.tobytes(), "from_coo y " + what
+                stats["coo"] = stats.get("coo", 0) + 1
     if case % 25 == 24:
         print(f"{case + 1} cases ok  {stats}", flush=True)
 print(f"all {cases} cases passed (seed {seed}): {stats}")
