@@ -255,71 +255,6 @@ extern "C" int spmv_hip_hll_plan_check(const HLLMatrix *hll, int total_rows, int
     return 0;
 }
 
-// Hacks [hack0, hack1) of the matrix, i.e. rows [32 hack0, min(32 hack1, total_rows)): one
-// rank's share under the reference's hack partitioner (prepare_thread_distribution_hll,
-// src/hll_matrix.c:410-540); y stays full length, the kernels write this handle's rows.
-extern "C" int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
-                                        spmv_hll_dev **out) {
-    if (need_device()) return -1;
-    if (!hll || !out) return fail("hll_upload: NULL argument");
-    *out = nullptr;
-    if ((unsigned long long)N * 8 >= (1ull << 32))
-        return fail("hll_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
-    const int Hall = hll->num_blocks;
-    if (Hall != (total_rows + kHack - 1) / kHack)
-        return fail("hll_upload: %d hacks do not match %d rows", Hall, total_rows);
-    if (hack0 < 0 || hack1 < hack0 || hack1 > Hall)
-        return fail("hll_upload: bad hack range [%d, %d) of %d", hack0, hack1, Hall);
-    const int H = hack1 - hack0;
-    const int row0 = hack0 * kHack;
-    const int rows = std::min(hack1 * kHack, total_rows) - std::min(row0, total_rows);
-
-    std::vector<int> mz((size_t)H, 0);
-    for (int h = 0; h < H; ++h) {
-        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
-        const int expect = (hack0 + h == Hall - 1) ? total_rows - (hack0 + h) * kHack : kHack;
-        if (b->M != expect) return fail("hll_upload: hack %d holds %d rows, expected %d", hack0 + h, b->M, expect);
-        if (b->MAXNZ < 0 || (b->MAXNZ > 0 && (!b->JA || !b->AS)))
-            return fail("hll_upload: hack %d is malformed", hack0 + h);
-        mz[h] = b->MAXNZ;
-        const long long s = (long long)b->M * b->MAXNZ;
-        for (long long k = 0; k < s; ++k)
-            if ((unsigned)b->JA[k] >= (unsigned)N)
-                return fail("hll_upload: column index %d in hack %d is outside [0, %d)", b->JA[k], hack0 + h, N);
-    }
-    std::vector<long long> off;
-    long long true_slots = 0;
-    const long long S = hll_offsets(rows, mz, off, true_slots);
-    if (S > (1LL << 40)) return fail("hll_upload: %lld padded slots is unreasonable", S);
-
-    // pack every hack into one flat pair of host arrays, then two copies
-    std::vector<int> ja((size_t)S + kPad, 0);
-    std::vector<double> as((size_t)S + kPad, 0.0);
-    for (int h = 0; h < H; ++h) {
-        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
-        const size_t s = (size_t)b->M * b->MAXNZ;
-        if (!s) continue;
-        memcpy(&ja[(size_t)off[h]], b->JA, s * sizeof(int));
-        memcpy(&as[(size_t)off[h]], b->AS, s * sizeof(double));
-    }
-    spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
-    if (!m) return fail("hll_upload: out of host memory");
-    int rc = upload_array(&m->JA, ja.data(), ja.size(), 0);
-    if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
-    if (!rc) rc |= hll_finish_handle(m, rows, N, off, mz, true_slots, true, ja.data(), total_rows, row0);
-    if (rc) {
-        spmv_hip_hll_free(m);
-        return -1;
-    }
-    *out = m;
-    return 0;
-}
-
-extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
-    if (!hll) return fail("hll_upload: NULL argument");
-    return spmv_hip_hll_upload_part(hll, total_rows, N, 0, hll->num_blocks, out);
-}
-
 namespace {
 
 // x-window plan of a device-resident slab, built by plan_count / plan_fill.  Returns 1 when the handle
@@ -408,6 +343,79 @@ int hll_plan_on_device(spmv_hll_dev *m, int total_rows, const std::vector<long l
 }
 
 }  // namespace
+
+// Hacks [hack0, hack1) of the matrix, i.e. rows [32 hack0, min(32 hack1, total_rows)): one
+// rank's share under the reference's hack partitioner (prepare_thread_distribution_hll,
+// src/hll_matrix.c:410-540); y stays full length, the kernels write this handle's rows.
+extern "C" int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
+                                        spmv_hll_dev **out) {
+    if (need_device()) return -1;
+    if (!hll || !out) return fail("hll_upload: NULL argument");
+    *out = nullptr;
+    if ((unsigned long long)N * 8 >= (1ull << 32))
+        return fail("hll_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
+    const int Hall = hll->num_blocks;
+    if (Hall != (total_rows + kHack - 1) / kHack)
+        return fail("hll_upload: %d hacks do not match %d rows", Hall, total_rows);
+    if (hack0 < 0 || hack1 < hack0 || hack1 > Hall)
+        return fail("hll_upload: bad hack range [%d, %d) of %d", hack0, hack1, Hall);
+    const int H = hack1 - hack0;
+    const int row0 = hack0 * kHack;
+    const int rows = std::min(hack1 * kHack, total_rows) - std::min(row0, total_rows);
+
+    std::vector<int> mz((size_t)H, 0);
+    for (int h = 0; h < H; ++h) {
+        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
+        const int expect = (hack0 + h == Hall - 1) ? total_rows - (hack0 + h) * kHack : kHack;
+        if (b->M != expect) return fail("hll_upload: hack %d holds %d rows, expected %d", hack0 + h, b->M, expect);
+        if (b->MAXNZ < 0 || (b->MAXNZ > 0 && (!b->JA || !b->AS)))
+            return fail("hll_upload: hack %d is malformed", hack0 + h);
+        mz[h] = b->MAXNZ;
+        const long long s = (long long)b->M * b->MAXNZ;
+        for (long long k = 0; k < s; ++k)
+            if ((unsigned)b->JA[k] >= (unsigned)N)
+                return fail("hll_upload: column index %d in hack %d is outside [0, %d)", b->JA[k], hack0 + h, N);
+    }
+    std::vector<long long> off;
+    long long true_slots = 0;
+    const long long S = hll_offsets(rows, mz, off, true_slots);
+    if (S > (1LL << 40)) return fail("hll_upload: %lld padded slots is unreasonable", S);
+
+    // pack every hack into one flat pair of host arrays, then two copies
+    std::vector<int> ja((size_t)S + kPad, 0);
+    std::vector<double> as((size_t)S + kPad, 0.0);
+    for (int h = 0; h < H; ++h) {
+        const ELLPACKBlock *b = &hll->blocks[hack0 + h];
+        const size_t s = (size_t)b->M * b->MAXNZ;
+        if (!s) continue;
+        memcpy(&ja[(size_t)off[h]], b->JA, s * sizeof(int));
+        memcpy(&as[(size_t)off[h]], b->AS, s * sizeof(double));
+    }
+    spmv_hll_dev *m = new (std::nothrow) spmv_hll_dev();
+    if (!m) return fail("hll_upload: out of host memory");
+    int rc = upload_array(&m->JA, ja.data(), ja.size(), 0);
+    if (!rc) rc |= upload_array(&m->AS, as.data(), as.size(), 0);
+    int planned = 0;  // the x-window plan on the device where it applies, else by the host builder from `ja`
+    if (!rc && g_stream_local && g_plan_on_device && true_slots > 0) {
+        planned = hll_plan_on_device(m, rows, off, mz);
+        if (planned < 0) rc = -1;
+    }
+    if (!rc) rc |= hll_finish_handle(m, rows, N, off, mz, true_slots, true, planned ? nullptr : ja.data(), total_rows, row0);
+    if (!rc && planned)
+        m->device_bytes += (size_t)m->local_blocks * 32 + ((size_t)m->local_lines + kLocalLinesMax) * 4 +
+                           ((size_t)S + kPad) * 2;
+    if (rc) {
+        spmv_hip_hll_free(m);
+        return -1;
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
+    if (!hll) return fail("hll_upload: NULL argument");
+    return spmv_hip_hll_upload_part(hll, total_rows, N, 0, hll->num_blocks, out);
+}
 
 // HLL built on the device from a resident CSR matrix (whole matrix, fp64).
 extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out) {
