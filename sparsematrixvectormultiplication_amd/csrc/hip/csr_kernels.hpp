@@ -65,14 +65,7 @@ __device__ __forceinline__ T gather(const T *__restrict__ x, int c) {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(x) + off);
 }
 
-// Workgroup ids are dealt round-robin over the 8 XCDs; give each XCD one
-// contiguous eighth of the work so that its private L2 sees one window of x
-// instead of all eight XCDs caching the same window.
-__device__ __forceinline__ int xcd_contiguous(int bid, int per_xcd) {
-    return (bid & 7) * per_xcd + (bid >> 3);
-}
-
-// Chunked variant: XCD x (= id & 7, ids are dealt round-robin over the XCDs) takes
+// Workgroup ids are dealt round-robin over the 8 XCDs, each with its own L2.  XCD x (= id & 7) takes
 // runs of `chunk` consecutive blocks, the eight XCDs sit on eight neighbouring
 // runs.  chunk = 0 keeps dispatch order (neighbouring blocks on different XCDs:
 // every L2 sees the x window of ALL resident blocks); a chunk of a few hundred
