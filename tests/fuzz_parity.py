@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: many small matrices of random shape (banded / scattered /
 mixed, empty rows, long rows, unsorted and repeated columns, fp64 and fp32, row blocks), the fast
-path of both formats against the oracle.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+path of both formats against the oracle.  Usage: python tests/fuzz_parity.py [cases] [seed]
+(lives under tests/ because it checks against the oracle; run by test_randomised_parity_sweep)"""
 import os
 import sys
 
@@ -9,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sparsematrixvectormultiplication_amd as sp  # noqa: E402
 from _util import assert_parity  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402

@@ -131,11 +131,11 @@ print("ok")
 
 @pytest.mark.gpu
 def test_randomised_parity_sweep(gpu):
-    """tools/fuzz_parity.py: 150 random small matrices (banded / scattered / mixed, empty and long
+    """tests/fuzz_parity.py: 150 random small matrices (banded / scattered / mixed, empty and long
     rows, unsorted and repeated columns, fp64 / fp32, row blocks) through the fast path of both
     formats against the oracle."""
     import sys
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "150", "11"],
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "150", "11"],
                           capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert proc.returncode == 0, proc.stdout[-1500:] + proc.stderr[-3000:]
     assert "all 150 cases passed" in proc.stdout
