@@ -139,3 +139,33 @@ def test_randomised_parity_sweep(gpu):
                           capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert proc.returncode == 0, proc.stdout[-1500:] + proc.stderr[-3000:]
     assert "all 150 cases passed" in proc.stdout
+
+
+@pytest.mark.gpu
+def test_tuning_through_the_environment(gpu):
+    """SPMV_TUNING="key=value,..." is read by spmv_hip_init: forcing the gather kernel through the environment
+    changes which kernel runs (same result), an unknown key makes init fail loudly."""
+    import sys
+    code = r'''
+import numpy as np, sys
+import sparsematrixvectormultiplication_amd as sp
+sys.path.insert(0, "tests")
+from _util import banded_csr
+sp.hip_init(0)
+rng = np.random.default_rng(1)
+rp, col, val = banded_csr(rng, 3000, 3000, 20, 100)
+with sp.CsrDevice(3000, 3000, rp, col, val) as d:
+    print("BLOCKS", d.info()["local_blocks"], "SUM", repr(float(np.sum(d.spmv(np.ones(3000))))))
+'''
+    outs = {}
+    for tag, env in (("default", {}), ("no_plan", {"SPMV_TUNING": "stream_local=0,stream_cap=4096"})):
+        proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                              env={**os.environ, **env})
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        line = [ln for ln in proc.stdout.splitlines() if ln.startswith("BLOCKS")][-1].split()
+        outs[tag] = (int(line[1]), float(line[3]))
+    assert outs["default"][0] > 0 and outs["no_plan"][0] == 0
+    assert abs(outs["default"][1] - outs["no_plan"][1]) <= 1e-9 * max(1.0, abs(outs["default"][1]))
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                          env={**os.environ, "SPMV_TUNING": "no_such_knob=1"})
+    assert proc.returncode != 0 and "unknown key" in (proc.stderr + proc.stdout)
