@@ -210,6 +210,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     const int e0 = row_ptr[row0], e1 = row_ptr[row1];
     const long long nz = (long long)e1 - e0;
     if (nz < 0) return fail("csr_upload: row_ptr is not monotone");
+    if (nz > 0x7fffffffLL - kPad) return fail("csr_upload: %lld entries exceed the 32-bit entry index of the kernels", nz);
     if (nz > 0 && !adopt_col && (!col_idx || !values)) return fail("csr_upload: col_idx / values are NULL");
     if ((unsigned long long)N * sizeof(T) >= (1ull << 32))
         return fail("csr_upload: N = %d exceeds the 32-bit gather offset range of the kernels", N);
