@@ -262,6 +262,26 @@ int spmv_hip_hll_step_time(spmv_hll_dev *m, int variant, const int *bounds, int 
 int spmv_hip_csr_power_iterate(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_graph,
                                double *lambda, float *ms_total);
 
+/* N4, second half -- the halo exchange of an iterated method: a rank needs only the entries of x its rows'
+ * columns touch (its own range plus a halo on banded matrices), not the whole all-gathered vector.
+ *   spmv_hip_csr_needed_ranges   those entries as at most max_ranges ascending ranges [lo, hi) (ranges[2 * max]),
+ *                                from the handle's x-window plan; the whole vector when it has none
+ *   spmv_hip_halo_plan           pure host logic, identical on every rank: from every rank's ranges (counts[ranks],
+ *                                ranges[ranks * 2 * stride]) and the ownership bounds, the (peer, lo, hi) triples
+ *                                this rank sends and receives (send / recv [3 * max_segments])
+ *   spmv_hip_comm_halo_setup     collective: all-gathers the ranks' needs, runs the plan, keeps the segments
+ *   spmv_hip_comm_halo_exchange  one group of ncclSend / ncclRecv on those segments, in place in d_vec
+ *   spmv_hip_comm_halo_info      values sent / received per exchange, peers talked to
+ *   spmv_hip_csr_power_iterate_halo   the power iteration with that exchange: partial norms + one all-reduce,
+ *                                every rank scales its own range of x, halo segments of x travel */
+int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count);
+int spmv_hip_halo_plan(int ranks, int rank, const int *bounds, const int *counts, const int *ranges, int stride,
+                       int max_segments, int *send, int *nsend, int *recv, int *nrecv);
+int spmv_hip_comm_halo_setup(const spmv_csr_dev *m, const int *bounds);
+int spmv_hip_comm_halo_exchange(void *d_vec, int value_bytes, void *stream);
+int spmv_hip_comm_halo_info(long long *send_values, long long *recv_values, int *peers);
+int spmv_hip_csr_power_iterate_halo(spmv_csr_dev *m, int variant, int iters, double *lambda, float *ms_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,6 +189,13 @@ _PROTOTYPES = {
     "spmv_hip_csr_plan_check": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p]),
     "spmv_hip_csr_power_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, c_double_p,
                                              c_float_p]),
+    "spmv_hip_csr_needed_ranges": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
+    "spmv_hip_halo_plan": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, C.c_int, C.c_int, c_int_p, c_int_p,
+                                     c_int_p, c_int_p]),
+    "spmv_hip_comm_halo_setup": (C.c_int, [C.c_void_p, c_int_p]),
+    "spmv_hip_comm_halo_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "spmv_hip_comm_halo_info": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_int_p]),
+    "spmv_hip_csr_power_iterate_halo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_float_p]),
     "spmv_hip_partition_hacks": (C.c_int, [C.POINTER(HLLMatrix), C.c_int, c_int_p]),
     "spmv_hip_hll_upload_part": (C.c_int, [C.POINTER(HLLMatrix), C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p)]),

@@ -404,3 +404,274 @@ extern "C" int spmv_hip_csr_power_iterate(spmv_csr_dev *m, int variant, int iter
     (void)hipFree(d_norm);
     return rc;
 }
+
+// ------------------------------------------------------------- halo exchange
+// SURVEY.md 8(f) N4, second half.  In an iterated method a rank does not need the whole of x, only the
+// entries its rows' columns touch; on banded matrices that is its own range plus a halo (nlpkkt-like
+// matrix on 8 ranks: 14-15 % of x comes from other ranks, against the 87.5 % an all-gather delivers).
+// Three pieces: what a handle needs (from its x-window plan), who sends what to whom (pure host
+// logic, identical on every rank), and the exchange itself (one group of ncclSend / ncclRecv on
+// contiguous segments of the vector: no packing, the segments are in place on both sides).
+namespace {
+
+struct halo_segment {
+    int peer, lo, hi;  // vector entries [lo, hi) to / from `peer`
+};
+std::vector<halo_segment> g_halo_send, g_halo_recv;
+bool g_halo_ready = false;
+
+// merge sorted, possibly touching ranges; then close the smallest gaps until at most max_ranges remain
+void squeeze_ranges(std::vector<std::pair<int, int>> &r, int max_ranges) {
+    std::vector<std::pair<int, int>> out;
+    for (const auto &p : r) {
+        if (!out.empty() && p.first <= out.back().second) out.back().second = std::max(out.back().second, p.second);
+        else out.push_back(p);
+    }
+    while ((int)out.size() > std::max(1, max_ranges)) {
+        size_t best = 1;
+        for (size_t k = 2; k < out.size(); ++k)
+            if (out[k].first - out[k - 1].second < out[best].first - out[best - 1].second) best = k;
+        out[best - 1].second = out[best].second;
+        out.erase(out.begin() + (long)best);
+    }
+    r.swap(out);
+}
+
+}  // namespace
+
+// The entries of x the handle's rows touch, as at most max_ranges ascending ranges [lo, hi) (128-byte line
+// granularity; small gaps are closed when there are more).  From the x-window plan's line lists; a handle
+// without a plan reports the whole vector.
+extern "C" int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count) {
+    if (need_device()) return -1;
+    if (!m || !ranges || !count || max_ranges < 1) return fail("csr_needed_ranges: bad arguments");
+    std::vector<std::pair<int, int>> r;
+    if (m->local_blocks <= 0 || m->num_long > 0) {
+        r.emplace_back(0, m->N);  // no plan, or rows outside it: everything
+    } else {
+        std::vector<int> lines((size_t)m->local_lines);
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        if (!lines.empty())
+            HIP_TRY(hipMemcpy(lines.data(), m->lines, lines.size() * sizeof(int), hipMemcpyDeviceToHost));
+        std::sort(lines.begin(), lines.end());
+        lines.erase(std::unique(lines.begin(), lines.end()), lines.end());
+        const int per_line = kLineBytes / m->value_bytes;
+        for (int l : lines) {
+            const int lo = l * per_line, hi = (int)std::min<long long>((long long)(l + 1) * per_line, m->N);
+            if (!r.empty() && r.back().second == lo) r.back().second = hi;
+            else r.emplace_back(lo, hi);
+        }
+        squeeze_ranges(r, max_ranges);
+    }
+    *count = (int)r.size();
+    for (size_t k = 0; k < r.size(); ++k) {
+        ranges[2 * k] = r[k].first;
+        ranges[2 * k + 1] = r[k].second;
+    }
+    return 0;
+}
+
+// Pure host logic, the same on every rank: rank q owns entries [bounds[q], bounds[q + 1]); rank p needs
+// counts[p] ranges at ranges + p * 2 * stride.  Out (triples peer, lo, hi; ascending per peer): what `rank`
+// sends (its own entries that a peer needs) and what it receives (entries it needs that a peer owns).
+extern "C" int spmv_hip_halo_plan(int ranks, int rank, const int *bounds, const int *counts, const int *ranges,
+                                  int stride, int max_segments, int *send, int *nsend, int *recv, int *nrecv) {
+    if (ranks < 1 || rank < 0 || rank >= ranks || !bounds || !counts || !ranges || !send || !nsend || !recv || !nrecv)
+        return fail("halo_plan: bad arguments");
+    int ns = 0, nr = 0;
+    auto clip = [&](int owner, int lo, int hi, int &a, int &b) {
+        a = std::max(lo, bounds[owner]);
+        b = std::min(hi, bounds[owner + 1]);
+        return a < b;
+    };
+    for (int p = 0; p < ranks; ++p) {
+        if (p == rank) continue;
+        for (int k = 0; k < counts[p]; ++k) {  // what p needs of mine
+            int a, b;
+            if (!clip(rank, ranges[(p * stride + k) * 2], ranges[(p * stride + k) * 2 + 1], a, b)) continue;
+            if (ns >= max_segments) return fail("halo_plan: more than %d segments to send", max_segments);
+            send[3 * ns] = p;
+            send[3 * ns + 1] = a;
+            send[3 * ns + 2] = b;
+            ++ns;
+        }
+    }
+    for (int q = 0; q < ranks; ++q) {
+        if (q == rank) continue;
+        for (int k = 0; k < counts[rank]; ++k) {  // what I need of q's
+            int a, b;
+            if (!clip(q, ranges[(rank * stride + k) * 2], ranges[(rank * stride + k) * 2 + 1], a, b)) continue;
+            if (nr >= max_segments) return fail("halo_plan: more than %d segments to receive", max_segments);
+            recv[3 * nr] = q;
+            recv[3 * nr + 1] = a;
+            recv[3 * nr + 2] = b;
+            ++nr;
+        }
+    }
+    *nsend = ns;
+    *nrecv = nr;
+    return 0;
+}
+
+namespace {
+constexpr int kHaloRanges = 32;      // ranges a rank publishes
+constexpr int kHaloSegments = 4096;  // segments a rank sends / receives
+}  // namespace
+
+// Collective: every rank publishes what its handle needs (all-gather of a small fixed-size record), derives
+// its send / receive segments with spmv_hip_halo_plan, and keeps them for spmv_hip_comm_halo_exchange.
+extern "C" int spmv_hip_comm_halo_setup(const spmv_csr_dev *m, const int *bounds) {
+    if (need_device()) return -1;
+    if (!g_comm) return fail("comm_halo_setup: no communicator");
+    if (!m || !bounds) return fail("comm_halo_setup: NULL argument");
+    g_halo_ready = false;
+    constexpr int kRecord = 1 + 2 * kHaloRanges;
+    std::vector<int> mine(kRecord, 0), all((size_t)kRecord * g_comm_size, 0);
+    if (spmv_hip_csr_needed_ranges(m, kHaloRanges, mine.data() + 1, &mine[0])) return -1;
+    int *d_all = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_all, all.size() * sizeof(int)));
+    int rc = 0;
+    do {
+        hipError_t e = hipMemcpy(d_all + (size_t)g_comm_rank * kRecord, mine.data(), kRecord * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = fail("comm_halo_setup: copy failed: %s", hipGetErrorString(e)); break; }
+        ncclResult_t n = ncclAllGather(d_all + (size_t)g_comm_rank * kRecord, d_all, kRecord, ncclInt, g_comm, g_stream);
+        if (n != ncclSuccess) { rc = fail("comm_halo_setup: ncclAllGather failed: %s", ncclGetErrorString(n)); break; }
+        e = hipStreamSynchronize(g_stream);
+        if (e == hipSuccess) e = hipMemcpy(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail("comm_halo_setup: gather failed: %s", hipGetErrorString(e)); break; }
+        std::vector<int> counts((size_t)g_comm_size), ranges((size_t)g_comm_size * 2 * kHaloRanges);
+        for (int p = 0; p < g_comm_size; ++p) {
+            counts[p] = all[(size_t)p * kRecord];
+            memcpy(&ranges[(size_t)p * 2 * kHaloRanges], &all[(size_t)p * kRecord + 1], 2 * kHaloRanges * sizeof(int));
+        }
+        std::vector<int> send(3 * kHaloSegments), recv(3 * kHaloSegments);
+        int ns = 0, nr = 0;
+        rc = spmv_hip_halo_plan(g_comm_size, g_comm_rank, bounds, counts.data(), ranges.data(), kHaloRanges,
+                                kHaloSegments, send.data(), &ns, recv.data(), &nr);
+        if (rc) break;
+        g_halo_send.assign((size_t)ns, halo_segment{});
+        g_halo_recv.assign((size_t)nr, halo_segment{});
+        for (int k = 0; k < ns; ++k) g_halo_send[k] = halo_segment{send[3 * k], send[3 * k + 1], send[3 * k + 2]};
+        for (int k = 0; k < nr; ++k) g_halo_recv[k] = halo_segment{recv[3 * k], recv[3 * k + 1], recv[3 * k + 2]};
+        g_halo_ready = true;
+    } while (0);
+    (void)hipFree(d_all);
+    return rc;
+}
+
+// values this rank sends / receives per exchange, and the number of peers it talks to
+extern "C" int spmv_hip_comm_halo_info(long long *send_values, long long *recv_values, int *peers) {
+    if (!g_halo_ready) return fail("comm_halo_info: spmv_hip_comm_halo_setup has not been called");
+    long long s = 0, r = 0;
+    std::vector<int> seen;
+    for (const auto &g : g_halo_send) { s += g.hi - g.lo; seen.push_back(g.peer); }
+    for (const auto &g : g_halo_recv) { r += g.hi - g.lo; seen.push_back(g.peer); }
+    std::sort(seen.begin(), seen.end());
+    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+    if (send_values) *send_values = s;
+    if (recv_values) *recv_values = r;
+    if (peers) *peers = (int)seen.size();
+    return 0;
+}
+
+// The exchange: every segment is contiguous in the vector on both sides, so it is one group of sends and
+// receives straight out of / into d_vec (a full-length vector; each rank's own range holds its values).
+extern "C" int spmv_hip_comm_halo_exchange(void *d_vec, int value_bytes, void *stream) {
+    if (need_device()) return -1;
+    if (!g_comm || !g_halo_ready) return fail("comm_halo_exchange: no communicator / no halo plan");
+    if (!d_vec || (value_bytes != 4 && value_bytes != 8)) return fail("comm_halo_exchange: bad arguments");
+    hipStream_t s = stream ? (hipStream_t)stream : g_stream;
+    const ncclDataType_t dt = value_bytes == 8 ? ncclDouble : ncclFloat;
+    if (g_halo_send.empty() && g_halo_recv.empty()) return 0;
+    NCCL_TRY(ncclGroupStart());
+    for (const auto &g : g_halo_send)
+        NCCL_TRY(ncclSend((char *)d_vec + (size_t)g.lo * value_bytes, (size_t)(g.hi - g.lo), dt, g.peer, g_comm, s));
+    for (const auto &g : g_halo_recv)
+        NCCL_TRY(ncclRecv((char *)d_vec + (size_t)g.lo * value_bytes, (size_t)(g.hi - g.lo), dt, g.peer, g_comm, s));
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+}
+
+namespace {
+
+// own rows only: sum of squares -> part[], then one workgroup folds them into sum[0]
+__global__ __launch_bounds__(kBlock) void fold_partials(const double *__restrict__ part, int nparts, double *__restrict__ sum) {
+    __shared__ double wave_sum[kBlock / 64];
+    double acc = 0;
+    for (int k = threadIdx.x; k < nparts; k += kBlock) acc += part[k];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = wave_sum[0];
+        for (int w = 1; w < kBlock / 64; ++w) s += wave_sum[w];
+        sum[0] = s;
+    }
+}
+
+__global__ void norm_from_sum(const double *__restrict__ sum, double *__restrict__ norm) {
+    const double nrm = sqrt(sum[0]);
+    norm[0] = nrm;
+    norm[1] = nrm > 0 ? 1.0 / nrm : 0.0;
+}
+
+template <typename T>
+int power_iterations_halo(spmv_csr_dev *m, int variant, int iters, double *d_part, double *d_sum, double *d_norm) {
+    const long long n = m->M_local;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(kNormBlocks, (n + kBlock - 1) / kBlock));
+    T *y_own = (T *)m->y + m->row0, *x_own = (T *)m->x + m->row0;
+    for (int i = 0; i < iters; ++i) {
+        if (csr_launch_any(m, variant, m->x, m->y, g_stream)) return -1;
+        hipLaunchKernelGGL((norm2_partial<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)y_own, n, d_part);
+        hipLaunchKernelGGL(fold_partials, dim3(1), dim3(kBlock), 0, g_stream, d_part, grid, d_sum);
+        if (g_comm) NCCL_TRY(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, g_comm, g_stream));
+        hipLaunchKernelGGL(norm_from_sum, dim3(1), dim3(1), 0, g_stream, d_sum, d_norm);
+        hipLaunchKernelGGL((scale_into<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)y_own, n, d_norm, x_own);
+        if (g_comm && spmv_hip_comm_halo_exchange(m->x, m->value_bytes, g_stream)) return -1;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// spmv_hip_csr_power_iterate with the halo exchange instead of the all-gatherv: every rank keeps only its
+// own rows of y; the norm is one all-reduce of the ranks' partial sums of squares, each rank scales its
+// own range of x and the halo segments of x travel (after spmv_hip_comm_halo_setup).  y holds only this
+// rank's rows of the last A x on return, x its own range and its halo.
+extern "C" int spmv_hip_csr_power_iterate_halo(spmv_csr_dev *m, int variant, int iters, double *lambda, float *ms_total) {
+    if (need_device()) return -1;
+    if (!m || iters <= 0) return fail("power_iterate_halo: bad arguments");
+    if (m->M_total != m->N) return fail("power_iterate_halo: needs a square matrix (%d x %d)", m->M_total, m->N);
+    if (g_comm && !g_halo_ready) return fail("power_iterate_halo: call spmv_hip_comm_halo_setup first");
+    double *d_part = nullptr, *d_sum = nullptr, *d_norm = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    do {
+        hipError_t e = hipMalloc((void **)&d_part, kNormBlocks * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_sum, sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_norm, 2 * sizeof(double));
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
+        if (e != hipSuccess) { rc = fail("power_iterate_halo: setup failed: %s", hipGetErrorString(e)); break; }
+        rc = m->value_bytes == 8 ? power_iterations_halo<double>(m, variant, iters, d_part, d_sum, d_norm)
+                                 : power_iterations_halo<float>(m, variant, iters, d_part, d_sum, d_norm);
+        if (rc) break;
+        e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        double nrm[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpy(nrm, d_norm, sizeof nrm, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail("power_iterate_halo: run failed: %s", hipGetErrorString(e)); break; }
+        if (lambda) *lambda = nrm[0];
+        if (ms_total) *ms_total = ms;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_part);
+    (void)hipFree(d_sum);
+    (void)hipFree(d_norm);
+    return rc;
+}

@@ -196,6 +196,13 @@ class CsrDevice(_Handle):
                "csr_power_iterate")
         return float(lam.value), float(ms.value)
 
+    def power_iterate_halo(self, iters, variant=CSR_AUTO):
+        """power_iterate with the halo exchange (NativeComm.halo_setup first when a communicator exists)."""
+        lam, ms = C.c_double(0), C.c_float(0)
+        _check(nat.lib().spmv_hip_csr_power_iterate_halo(self.h, int(variant), int(iters), C.byref(lam), C.byref(ms)),
+               "csr_power_iterate_halo")
+        return float(lam.value), float(ms.value)
+
     def get_x(self):
         x = np.empty(self.N, dtype=self.dtype)
         _check(nat.lib().spmv_hip_memcpy_d2h(x.ctypes.data_as(C.c_void_p), C.c_void_p(self.x_ptr), x.nbytes),

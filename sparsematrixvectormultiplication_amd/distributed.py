@@ -71,6 +71,40 @@ def allgatherv_rows_torch(y_full, bounds, group=None):
         dist.broadcast(y_full[int(bounds[r]):int(bounds[r + 1])], src=r, group=group)
 
 
+HALO_MAX_RANGES = 32
+
+
+def needed_ranges(dev, max_ranges=HALO_MAX_RANGES):
+    """[(lo, hi), ...]: the entries of x the handle's rows touch (spmv_hip_csr_needed_ranges)."""
+    buf = np.zeros(2 * max_ranges, dtype=np.int32)
+    n = C.c_int(0)
+    _check(nat.lib().spmv_hip_csr_needed_ranges(dev.h, int(max_ranges), buf.ctypes.data_as(nat.c_int_p), C.byref(n)),
+           "spmv_hip_csr_needed_ranges")
+    return [(int(buf[2 * k]), int(buf[2 * k + 1])) for k in range(n.value)]
+
+
+def halo_plan(rank, bounds, all_ranges, max_segments=4096):
+    """Who sends what to whom (spmv_hip_halo_plan): all_ranges[p] = rank p's needed ranges.  Returns
+    (send, recv), lists of (peer, lo, hi)."""
+    ranks = len(all_ranges)
+    stride = max(1, max(len(r) for r in all_ranges))
+    counts = np.array([len(r) for r in all_ranges], dtype=np.int32)
+    flat = np.zeros(ranks * 2 * stride, dtype=np.int32)
+    for p, rs in enumerate(all_ranges):
+        for k, (lo, hi) in enumerate(rs):
+            flat[(p * stride + k) * 2], flat[(p * stride + k) * 2 + 1] = lo, hi
+    b = np.ascontiguousarray(bounds, dtype=np.int32)
+    send, recv = np.zeros(3 * max_segments, np.int32), np.zeros(3 * max_segments, np.int32)
+    ns, nr = C.c_int(0), C.c_int(0)
+    if nat.lib().spmv_hip_halo_plan(ranks, int(rank), b.ctypes.data_as(nat.c_int_p), counts.ctypes.data_as(nat.c_int_p),
+                                    flat.ctypes.data_as(nat.c_int_p), stride, max_segments,
+                                    send.ctypes.data_as(nat.c_int_p), C.byref(ns), recv.ctypes.data_as(nat.c_int_p),
+                                    C.byref(nr)) != 0:
+        raise SpmvHipError(nat.lib().spmv_hip_last_error().decode())
+    trip = lambda a, n: [(int(a[3 * k]), int(a[3 * k + 1]), int(a[3 * k + 2])) for k in range(n)]
+    return trip(send, ns.value), trip(recv, nr.value)
+
+
 class NativeComm:
     """RCCL communicator owned by libspmv_amd.so (spmv_hip_comm_*)."""
 
@@ -100,6 +134,18 @@ class NativeComm:
         _check(nat.lib().spmv_hip_comm_autotune(C.c_void_p(d_y), b.ctypes.data_as(nat.c_int_p), int(value_bytes),
                                                 int(iters), C.byref(mode), ms), "spmv_hip_comm_autotune")
         return int(mode.value), float(ms[0]), float(ms[1])
+
+    def halo_setup(self, dev, bounds):
+        """Collective: publish what dev needs of x, derive this rank's send / receive segments."""
+        b = np.ascontiguousarray(bounds, dtype=np.int32)
+        _check(nat.lib().spmv_hip_comm_halo_setup(dev.h, b.ctypes.data_as(nat.c_int_p)), "spmv_hip_comm_halo_setup")
+        s, r, p = C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+        _check(nat.lib().spmv_hip_comm_halo_info(C.byref(s), C.byref(r), C.byref(p)), "spmv_hip_comm_halo_info")
+        return {"send_values": int(s.value), "recv_values": int(r.value), "peers": int(p.value)}
+
+    def halo_exchange(self, d_vec: int, value_bytes=8, stream: int = 0):
+        _check(nat.lib().spmv_hip_comm_halo_exchange(C.c_void_p(d_vec), int(value_bytes), C.c_void_p(stream)),
+               "spmv_hip_comm_halo_exchange")
 
     def close(self):
         nat.lib().spmv_hip_comm_destroy()

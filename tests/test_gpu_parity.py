@@ -882,3 +882,110 @@ def test_csr_from_coo_on_device_large_shuffled(gpu, oracle):
         x = rng.uniform(-1, 1, 40000)
         assert_parity(sc.spmv(x), oracle.csr_serial(ref.row_ptr, ref.col_idx, ref.values, x), ref.row_ptr,
                       ref.col_idx, ref.values, x, what="from_coo scattered")
+
+
+# ------------------------------------------------ halo exchange (N4, second half)
+def test_needed_ranges_cover_what_the_rows_touch(gpu):
+    from sparsematrixvectormultiplication_amd.distributed import needed_ranges
+    from _util import banded_csr
+    rng = np.random.default_rng(61)
+    M = N = 20000
+    row_ptr, col, val = banded_csr(rng, M, N, 25, 300, 0.02, far_frac=0.2)
+    for r0, r1 in ((0, M), (5000, 9000), (19000, M)):
+        with sp.CsrDevice(M, N, row_ptr, col, val, row0=r0, row1=r1) as dev:
+            assert dev.info()["local_blocks"] > 0
+            for cap in (32, 4, 1):
+                rs = needed_ranges(dev, cap)
+                assert 1 <= len(rs) <= cap and all(a < b for a, b in rs)
+                assert all(rs[k][1] < rs[k + 1][0] for k in range(len(rs) - 1))
+                touched = np.unique(col[row_ptr[r0]:row_ptr[r1]])
+                inside = np.zeros(N, bool)
+                for a, b in rs:
+                    inside[a:b] = True
+                assert inside[touched].all(), "a touched column lies outside the reported ranges"
+                if cap == 32:   # and not wildly more than needed: whole lines of touched columns plus closed gaps
+                    assert inside.sum() <= 16 * len(np.unique(touched // 16)) + 16 * 2000
+    row_ptr, col, val = random_csr(rng, 500, 30000, 20, 40, 0.0)      # no plan: everything
+    with sp.CsrDevice(500, 30000, row_ptr, col, val) as dev:
+        assert needed_ranges(dev) == [(0, 30000)]
+
+
+def test_power_iteration_with_halo_exchange_emulated_ranks(gpu, oracle):
+    """Three 'ranks' in one process on one GPU: each holds its row block, asks the library what it needs of x
+    (spmv_hip_csr_needed_ranges) and who sends what to whom (spmv_hip_halo_plan); the transport is emulated with
+    host copies.  Everything a rank does not own and did not receive is NaN, so a missing halo entry poisons the
+    result.  Against the single-handle power iteration."""
+    import ctypes as C
+    from sparsematrixvectormultiplication_amd.distributed import halo_plan, needed_ranges
+    from _util import banded_csr
+    rng = np.random.default_rng(62)
+    n = 9000
+    row_ptr, col, val = banded_csr(rng, n, n, 18, 120)
+    x0 = rng.uniform(0.5, 1.0, n)
+    iters = 5
+    with sp.CsrDevice(n, n, row_ptr, col, val) as whole:
+        whole.set_x(x0)
+        lam_ref, _ = whole.power_iterate(iters)
+        x_ref = whole.get_x()
+    bounds = sp.partition_rows(row_ptr, 3)
+    devs = [sp.CsrDevice(n, n, row_ptr, col, val, row0=int(bounds[r]), row1=int(bounds[r + 1])) for r in range(3)]
+    try:
+        needs = [needed_ranges(d) for d in devs]
+        plans = [halo_plan(r, bounds, needs) for r in range(3)]
+        assert sum(hi - lo for _, lo, hi in plans[1][1]) < n // 2, "banded matrix: the halo is a small part of x"
+        xs = []
+        for r in range(3):                                   # own range + halo of x0, NaN elsewhere
+            x = np.full(n, np.nan)
+            x[bounds[r]:bounds[r + 1]] = x0[bounds[r]:bounds[r + 1]]
+            for q, lo, hi in plans[r][1]:
+                x[lo:hi] = x0[lo:hi]
+            xs.append(x)
+        lam = 0.0
+        for _ in range(iters):
+            ys = []
+            for r, d in enumerate(devs):
+                d.set_x(xs[r])
+                d.run(sp.CSR_STREAM)
+                ys.append(d.get_y()[bounds[r]:bounds[r + 1]])
+                assert not np.any(np.isnan(ys[-1])), "a row read an x entry it was not given"
+            lam = float(np.sqrt(sum(np.sum(y * y) for y in ys)))       # partial sums + "all-reduce"
+            own = [y / lam for y in ys]
+            xs = []
+            for r in range(3):
+                x = np.full(n, np.nan)
+                x[bounds[r]:bounds[r + 1]] = own[r]
+                for q, lo, hi in plans[r][1]:                          # what q sends to r
+                    x[lo:hi] = own[q][lo - bounds[q]:hi - bounds[q]]
+                xs.append(x)
+        assert abs(lam - lam_ref) <= 1e-12 * lam_ref
+        for r in range(3):
+            seg = slice(bounds[r], bounds[r + 1])
+            assert np.max(np.abs(xs[r][seg] - x_ref[seg])) <= 1e-12 * np.max(np.abs(x_ref))
+    finally:
+        for d in devs:
+            d.close()
+
+
+def test_power_iteration_halo_single_rank_communicator(gpu):
+    """The RCCL side at world size 1: setup (all-gather of the needs record), an exchange with no peers, the
+    all-reduce of the norm; the halo loop then gives the plain loop's result bit for bit."""
+    from sparsematrixvectormultiplication_amd.distributed import NativeComm
+    from _util import banded_csr
+    rng = np.random.default_rng(63)
+    n = 4000
+    row_ptr, col, val = banded_csr(rng, n, n, 15, 80)
+    x0 = rng.uniform(0.5, 1.0, n)
+    with sp.CsrDevice(n, n, row_ptr, col, val) as dev:
+        dev.set_x(x0)
+        lam_plain, _ = dev.power_iterate(4, use_graph=False)
+        x_plain = dev.get_x()
+        comm = NativeComm(0, 1, lambda ident: ident)
+        try:
+            info = comm.halo_setup(dev, np.array([0, n], np.int32))
+            assert info == {"send_values": 0, "recv_values": 0, "peers": 0}
+            comm.halo_exchange(dev.x_ptr, 8)
+            dev.set_x(x0)
+            lam_halo, ms = dev.power_iterate_halo(4)
+            assert ms > 0 and lam_halo == lam_plain and dev.get_x().tobytes() == x_plain.tobytes()
+        finally:
+            comm.close()

@@ -78,3 +78,39 @@ def test_hll_plan_invariants_on_banded_matrices(mean, band, empty, far):
     row_ptr, col, val = random_csr(rng, 500, 30000, 40, 80, 0.0)
     r, c, v = coo_from_csr(row_ptr, col, val, rng)
     assert sp.hll_plan_check(sp.convert_to_hll(sp.PreMatrix.from_arrays(500, 30000, r, c, v)))["local_windows"] == 0
+
+
+def test_halo_plan_is_consistent_between_ranks():
+    """spmv_hip_halo_plan (pure host logic): what rank r sends to p is exactly what p receives from r, segment
+    by segment and in the same order; every needed entry outside a rank's own range is received exactly once;
+    nothing is exchanged for entries a rank owns itself."""
+    from sparsematrixvectormultiplication_amd.distributed import halo_plan
+    rng = np.random.default_rng(9)
+    for ranks in (1, 2, 3, 8):
+        n = 10000
+        cuts = np.sort(rng.choice(np.arange(1, n), ranks - 1, replace=False)) if ranks > 1 else np.array([], int)
+        bounds = np.concatenate([[0], cuts, [n]]).astype(np.int32)
+        if ranks >= 3:
+            bounds[2] = bounds[1]          # a rank that owns nothing
+        needs = []
+        for r in range(ranks):
+            k = int(rng.integers(0, 6))
+            pts = np.sort(rng.choice(n + 1, 2 * k, replace=False))
+            needs.append([(int(pts[2 * j]), int(pts[2 * j + 1])) for j in range(k)])
+        plans = [halo_plan(r, bounds, needs) for r in range(ranks)]
+        for r in range(ranks):
+            send, recv = plans[r]
+            for p in range(ranks):
+                to_p = [(lo, hi) for q, lo, hi in send if q == p]
+                from_r = [(lo, hi) for q, lo, hi in plans[p][1] if q == r]
+                assert to_p == from_r, (ranks, r, p)
+                assert all(bounds[r] <= lo < hi <= bounds[r + 1] for lo, hi in to_p)
+            got = np.zeros(n, int)
+            for q, lo, hi in recv:
+                assert q != r and bounds[q] <= lo < hi <= bounds[q + 1]
+                got[lo:hi] += 1
+            want = np.zeros(n, int)
+            for lo, hi in needs[r]:
+                want[lo:hi] = 1
+            want[bounds[r]:bounds[r + 1]] = 0
+            assert np.array_equal(got, want), (ranks, r)
