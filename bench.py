@@ -58,15 +58,41 @@ HOST_CORES = _host_cores()
 
 import numpy as np  # noqa: E402
 
-def measured_traffic(kernel, workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json,
-    written by tools/prof_traffic.py: FETCH_SIZE doubled per the gfx950 correction in
-    MI355X_MICROARCH.md + WRITE_SIZE), for the same kernel on the same workload; else None."""
+KERNEL_SOURCES = {  # the file a kernel's code lives in: a traffic measurement belongs to one revision of it
+    "csr": os.path.join(ROOT, "sparsematrixvectormultiplication_amd", "csrc", "hip", "csr_kernels.hpp"),
+    "hll": os.path.join(ROOT, "sparsematrixvectormultiplication_amd", "csrc", "hip", "hll_kernels.hpp"),
+}
+
+
+def kernel_source_sha(kernel):
+    import hashlib
+    path = KERNEL_SOURCES["hll" if kernel.startswith("hll") else "csr"]
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return table.get(f"{kernel}|{workload}")
-    except (OSError, ValueError):
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
         return None
+
+
+def measured_traffic(kernel, workload, format_bytes, blocks, table_path=None):
+    """(bytes, source) -- HBM bytes per launch of `kernel` on `workload` from the committed rocprofv3 PMC
+    passes (profiles/traffic.json, written by tools/prof_traffic.py: FETCH_SIZE doubled per the gfx950
+    correction in MI355X_MICROARCH.md + WRITE_SIZE, separate --pmc passes), or (None, reason).  The table
+    is NOT a measurement of this run: an entry is only handed out when it was taken on the same kernel
+    source revision (sha of the kernels header), the same bytes of the kernel's own format and the same
+    number of workgroups; anything else -- a rebuilt, retuned or re-planned kernel -- gets null."""
+    try:
+        table = json.load(open(table_path or os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    e = table.get(f"{kernel}|{workload}")
+    if not isinstance(e, dict):
+        return None, "no PMC pass recorded for this kernel on this workload"
+    if e.get("kernel_src_sha") != kernel_source_sha(kernel):
+        return None, "kernel source changed since the PMC pass (re-run tools/prof.sh + tools/prof_traffic.py)"
+    if int(e.get("format_bytes", -1)) != int(format_bytes) or int(e.get("blocks", -1)) != int(blocks):
+        return None, "format bytes / workgroups differ from the profiled run"
+    return int(e["bytes"]), (f"profiles/traffic.json <- {e.get('source', '?')} (rocprofv3 --pmc FETCH_SIZE x2 + "
+                             "WRITE_SIZE, separate passes; not measured in this run)")
 
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
@@ -90,6 +116,7 @@ def parse_args():
                    help="gloo-host: debug transport through host memory (several ranks may share one GPU)")
     p.add_argument("--check", action="store_true", help="every rank checks the gathered y against the oracle")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-cpu-sweep", action="store_true", help="skip the reference's thread sweep (main.c:18)")
     p.add_argument("--no-also", action="store_true", help="skip the cant CSR/HLL side measurements")
     p.add_argument("--cpu-iters", type=int, default=0, help="0 = size for ~10 s")
     return p.parse_args()
@@ -205,6 +232,61 @@ def cpu_baseline(wl, cpu_iters):
                       f"({nnz} nnz) after 5 warm-ups, x = 1"}, y
 
 
+REFERENCE_THREAD_SWEEP = (2, 4, 8, 16, 32, 40)  # main.c:18
+
+
+def _time_calls(fn, args, warm, iters):
+    for _ in range(warm):
+        fn(*args)
+    samples = []
+    for _ in range(iters):
+        t = time.perf_counter()
+        fn(*args)
+        samples.append(time.perf_counter() - t)
+    return float(np.mean(samples))
+
+
+def cpu_thread_sweep(wl, hll=None, iters=8):
+    """Optional extra fields of cpu_baseline: the reference's thread sweep (main.c:18,172: T in
+    {2,4,8,16,32,40}, here capped at the box's cores -- more threads than cores only measures the
+    scheduler) over its OpenMP kernels K2 spvm_csr_parallel / K3 spvm_csr_parallel_simd and, when a
+    host HLL is at hand, K6 spmv_hll / K7 spmv_hll_simd, each over the reference's own partition for
+    that T.  GFLOP/s with the CSR nnz (M1).  2 warm-ups + `iters` timed runs per cell."""
+    import ctypes as C
+    from oracle.oracle import Oracle, Reference, have_reference
+    import sparsematrixvectormultiplication_amd as sp
+
+    lib = Reference().L if have_reference() else Oracle().L
+    row_ptr, col, val = wl["row_ptr"], wl["col_full"], wl["val_full"]
+    M, nnz = wl["M"], int(row_ptr[-1])
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    val64 = np.ascontiguousarray(val, dtype=np.float64)
+    x = np.ones(wl["N"])
+    y = np.zeros(max(M, (hll.num_blocks * 32) if hll is not None else 0))
+    rows = []
+    for T in REFERENCE_THREAD_SWEEP:
+        if T > HOST_CORES or T > M:   # main.c:177 skips T > M
+            continue
+        cell = {"threads": T}
+        starts, ends = sp.prepare_thread_distribution(row_ptr, T, nnz)
+        a = (row_ptr.ctypes.data_as(ip), col.ctypes.data_as(ip), val64.ctypes.data_as(dp), x.ctypes.data_as(dp),
+             y.ctypes.data_as(dp), len(starts), starts.ctypes.data_as(ip), ends.ctypes.data_as(ip))
+        cell["csr"] = round(2.0 * nnz / _time_calls(lib.spvm_csr_parallel, a, 2, iters) / 1e9, 3)
+        cell["csr_simd"] = round(2.0 * nnz / _time_calls(lib.spvm_csr_parallel_simd, a, 2, iters) / 1e9, 3)
+        if hll is not None and T <= hll.num_blocks:
+            hs, he = sp.prepare_thread_distribution_hll(hll, T)
+            b = (hll.c.blocks, x.ctypes.data_as(dp), y.ctypes.data_as(dp), len(hs), hs.ctypes.data_as(ip),
+                 he.ctypes.data_as(ip))
+            cell["hll"] = round(2.0 * nnz / _time_calls(lib.spmv_hll, b, 2, iters) / 1e9, 3)
+            cell["hll_simd"] = round(2.0 * nnz / _time_calls(lib.spmv_hll_simd, b, 2, iters) / 1e9, 3)
+        rows.append(cell)
+    return {"unit": "GFLOP/s", "kind": "reference" if have_reference() else "port",
+            "kernels": "K2 spvm_csr_parallel, K3 spvm_csr_parallel_simd" +
+                       (", K6 spmv_hll, K7 spmv_hll_simd" if hll is not None else ""),
+            "threads_of_the_reference": list(REFERENCE_THREAD_SWEEP), "host_cores": HOST_CORES,
+            "timed_runs_per_cell": iters, "rows": rows}
+
+
 def cpu_baseline_hll(wl, cpu_iters):
     """The reference's OpenMP HLL kernel (spmv_hll, src/hll_matrix.c:376-408) over its own hack
     partition (prepare_thread_distribution_hll) on the host cores of this box; the compiled
@@ -249,7 +331,7 @@ def cpu_baseline_hll(wl, cpu_iters):
 
 
 # ----------------------------------------------------------------- side measurements
-def side_measurement(sp, synth, which, steps, warmup):
+def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
     """cant-like CSR / HLL on this GPU (BASELINE configs[1], [2]) and the same FEM-shaped
     generator scaled past the Infinity Cache; kernel-only event times."""
     if which == "fem_large_csr":
@@ -306,11 +388,49 @@ def side_measurement(sp, synth, which, steps, warmup):
         dev.set_x(x)
         info = dev.info()
         ms = dev.time(sp.HLL_LDS, warmup, steps, zero_y=True)
+    cpu = None
+    if cpu_sweep:
+        try:
+            cpu = cpu_thread_sweep(dict(row_ptr=row_ptr, col_full=col, val_full=val, M=M, N=M), hll)
+        except Exception as exc:
+            cpu = {"error": str(exc)}
     return {"workload": "cant-like fp64 HLL hack=32 (slots=%d; flops counted with the CSR nnz)" %
-            info["slots"], "algo_bytes": info["algo_bytes"],
+            info["slots"], "algo_bytes": info["algo_bytes"], "cpu_thread_sweep_csr_and_hll": cpu,
             "lds": {"gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
                     "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
                     "us": round(float(ms.mean()) * 1e3, 2)}}
+
+
+# ----------------------------------------------------------------- launcher
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N bench.py <same arguments>` as a CHILD process (never an exec: this process must
+    stay clear of the GPU and simply waits), one rank per GPU, rendezvous on 127.0.0.1.  The ranks'
+    stderr passes through; rank 0's JSON line is the only thing printed on stdout.  Returns the child's
+    exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"[bench] starting {n} ranks: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT, env=dict(os.environ))
+    last_json = None
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            last_json = line.strip()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if last_json is not None:
+        print(last_json, flush=True)
+    elif rc == 0:
+        log("[bench] the ranks exited without printing a result line")
+        rc = 1
+    return rc
 
 
 # ----------------------------------------------------------------- main
@@ -319,9 +439,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (before anything here has
+        # touched the GPU) and relay rank 0's JSON line
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import torch  # first, so that one HIP runtime serves torch and libspmv_amd.so alike
@@ -375,7 +497,7 @@ def main():
     dev.set_x(x)
 
     # the exchange step (N > 1): RCCL all-gatherv of y
-    comm, exchange, gather_mode = None, "none", 0
+    comm, exchange, gather_mode, rccl_ranks, autotune_ms = None, "none", 0, None, None
     if world > 1:
         exchange = args.exchange
         if exchange == "rccl":
@@ -388,7 +510,10 @@ def main():
                 comm = NativeComm(rank, world, share)
                 dev.step_time(bounds, variant, 0, 1)      # first exchange: fail here, not in the timed region
                 # which all-gatherv is faster on THIS node (grouped broadcasts vs padded all-gather)
+                rccl_ranks = comm.rccl_ranks()[1]
                 gather_mode, ms_b, ms_g = comm.autotune(dev.y_ptr, bounds, vb, 10)
+                autotune_ms = {"grouped_broadcasts": round(ms_b, 5),
+                               "padded_allgather_scatter": None if ms_g < 0 else round(ms_g, 5)}
                 log(f"[rank {rank}] all-gatherv: grouped broadcasts {ms_b * 1e3:.1f} us, padded all-gather "
                     f"{'rejected' if ms_g < 0 else f'{ms_g * 1e3:.1f} us'} -> mode {gather_mode}")
             except Exception as exc:  # both transports are RCCL; fall back to torch's
@@ -406,6 +531,7 @@ def main():
         if exchange == "gloo-host":
             y_host = torch.zeros(M, dtype=torch.float32 if vb == 4 else torch.float64)
         if exchange == "torch":
+            rccl_ranks = dist.get_world_size()  # torch's communicator (backend nccl = RCCL)
             y_t = torch.zeros(M, dtype=torch.float32 if vb == 4 else torch.float64, device="cuda")
             x_t = torch.ones(N, dtype=y_t.dtype, device="cuda")
             stream = torch.cuda.current_stream().cuda_stream
@@ -499,6 +625,7 @@ def main():
         if not err <= 1e-10:
             raise SystemExit(f"[rank {rank}] gathered y differs from the oracle: {err:.3e}")
     result = None
+    parity_failed = False
     if rank == 0:
         ms_step = wall_max / K * 1e3
         gflops = 2.0 * nnz_total / (wall_max / K) / 1e9
@@ -515,6 +642,9 @@ def main():
                        {0: stream_name, 1: "csr_thread_row", 2: "csr_vector<64,2>", 3: "csr_vector<L,1>",
                         4: stream_name}[variant if variant else info["auto_variant"]])
         moved = float(per_rank[slow, 5]) if kernel_name.endswith("_local") else float(per_rank[slow, 3])
+        traffic, traffic_source = (measured_traffic(kernel_name, wl["name"], moved,
+                                                    info["local_blocks"] or info["stream_blocks"])
+                                   if world == 1 else (None, "PMC passes are taken at N = 1 only"))
         result = {
             "metric": "SpMV GFLOP/s (2*nnz flops / step time); achieved HBM GB/s and % of 8 TB/s alongside",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -525,7 +655,9 @@ def main():
             "hbm_pct_of_8TBs": round(algo_total / (wall_max / K) / 1e9 / HBM_PEAK_GBPS * 100, 2),
             "config": {"workload": wl["name"] + (" HLL hack=32" if hll_mode else " CSR"),
                        "rows": M, "cols": N, "nnz": nnz_total, "x": "ones",
-                       "kernel": kernel_name, "parallelism": f"row-block x{world}" if world > 1 else "1 GPU",
+                       "workload_key": wl["name"],
+                       "kernel": kernel_name, "workgroups": int(info["local_blocks"] or info["stream_blocks"]),
+                       "parallelism": f"row-block x{world}" if world > 1 else "1 GPU",
                        "exchange": {"none": "none", "rccl": "RCCL all-gatherv(y), C-ABI communicator, " +
                                     ("one padded ncclAllGather + scatter" if gather_mode == 1 else
                                      "one ncclBroadcast per owner in a group") + " (picked by timing both)",
@@ -535,7 +667,7 @@ def main():
                        "device": dev_name},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic(kernel_name, wl["name"]),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(per_rank[slow, 3]),
                          # what the kernel's own format streams from HBM (2-byte local columns + line
                          # lists instead of 4-byte columns for csr_stream_local); `achieved` above is
@@ -549,20 +681,34 @@ def main():
         if world > 1:
             result["per_step_ms"] = {"kernel_max_over_ranks": round(float(per_rank[:, 1].max()), 5),
                                      "allgatherv_max_over_ranks": round(float(per_rank[:, 2].max()), 5)}
+            result["config"]["rccl_ranks"] = rccl_ranks          # what ncclCommCount reports (None: gloo-host)
+            result["config"]["allgatherv_autotune_ms"] = autotune_ms
+            result["config"]["rows_per_rank"] = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
 
     # CPU baseline + oracle check: rank 0, N = 1 only (bounded, ~10 s)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and vb == 8:
         wl["col_full"], wl["val_full"] = wl["col"], wl["val"]
         cb, y_cpu = cpu_baseline_hll(wl, args.cpu_iters) if hll_mode else cpu_baseline(wl, args.cpu_iters)
+        if not args.no_cpu_sweep:
+            try:
+                cb["thread_sweep"] = cpu_thread_sweep(wl, wl.get("hll"))
+            except Exception as exc:  # optional fields must never lose the headline line
+                cb["thread_sweep"] = {"error": str(exc)}
         result["cpu_baseline"] = cb
         scale = max(float(np.max(np.abs(y_cpu))), 1e-300)
-        result["parity_vs_cpu_reference"] = {"max_abs_diff_over_max_abs": float(np.max(np.abs(y_gpu - y_cpu)) / scale),
-                                             "gate": 1e-10}
+        diff = float(np.max(np.abs(y_gpu - y_cpu)) / scale)
+        result["parity_vs_cpu_reference"] = {"max_abs_diff_over_max_abs": diff, "gate": 1e-10,
+                                             "parity_ok": bool(diff <= 1e-10)}
+        if not diff <= 1e-10:  # a wrong-result kernel publishes no throughput
+            log(f"[bench] PARITY FAILURE: GPU y differs from the CPU reference by {diff:.3e} (gate 1e-10)")
+            result["value"] = None
+            result["invalid"] = "parity gate failed"
+            parity_failed = True
     if rank == 0 and world == 1 and not args.no_also and args.workload == "nlpkkt":
         dev.close()
         try:
             result["also"] = [side_measurement(sp, synth, "cant_csr", K, W),
-                              side_measurement(sp, synth, "cant_hll", K, W),
+                              side_measurement(sp, synth, "cant_hll", K, W, cpu_sweep=not (args.no_cpu_baseline or args.no_cpu_sweep)),
                               side_measurement(sp, synth, "fem_large_csr", K, W)]
         except Exception as exc:  # side numbers must never lose the headline line
             result["also"] = [{"error": str(exc)}]
@@ -573,6 +719,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result, default=lambda o: o.item() if hasattr(o, "item") else str(o)), flush=True)
+    if parity_failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -227,6 +227,8 @@ int spmv_hip_partition_hacks(const HLLMatrix *hll, int parts, int *bounds);
 int spmv_hip_comm_get_id(void *id_bytes);
 int spmv_hip_comm_init(const void *id_bytes, int rank, int nranks);
 int spmv_hip_comm_destroy(void);
+/* what RCCL reports for the communicator (ncclCommUserRank / ncclCommCount) */
+int spmv_hip_comm_info(int *rank, int *nranks);
 /* In-place all-gatherv of y over xGMI: rank r contributes
  * d_y[bounds[r] .. bounds[r+1]) and receives everybody else's rows, as one
  * grouped set of ncclBroadcast calls on `stream` (NULL = library stream).

@@ -204,6 +204,7 @@ _PROTOTYPES = {
     "spmv_hip_comm_get_id": (C.c_int, [C.c_void_p]),
     "spmv_hip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "spmv_hip_comm_destroy": (C.c_int, []),
+    "spmv_hip_comm_info": (C.c_int, [c_int_p, c_int_p]),
     "spmv_hip_comm_allgatherv": (C.c_int, [C.c_void_p, c_int_p, C.c_int, C.c_void_p]),
 }
 

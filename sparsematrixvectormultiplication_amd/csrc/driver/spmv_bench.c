@@ -9,6 +9,8 @@
  *   (main_cuda.cu:183-187), mean time / 2*nnz/t FLOPS / mean errors to
  *     <out>/spmv_results_hip.csv            (the reference's GPU schema, unchanged)
  *     <out>/spmv_results_hip_roofline.csv   (algorithmic GB/s, % of 8 TB/s)
+ *     <out>/spmv_results_hip_block_dim.csv  (the reference's launch-shape schema, main_cuda.cu:728)
+ *     <out>/spmv_results_hip_launch_shape.csv (lanes per row, stage, workgroups, kernel chosen)
  *
  * The comparison vector is the reference's serial CSR result.  That kernel is the
  * ORACLE (oracle/cpu_spmv.c) and is deliberately not part of libspmv_amd.so, so
@@ -194,6 +196,28 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
                 ci.local_blocks > 0 ? ci.stream_bytes : ci.algo_bytes,
                 hi.local_blocks > 0 ? "hll_lds_local" : "hll_lds",
                 hi.local_blocks > 0 ? hi.stream_bytes : hi.algo_bytes);
+        fclose(fp);
+    }
+    /* launch shapes (reference: write_block_result_to_csv, cuda_src/utility.cu:236-261, called at
+     * main_cuda.cu:728 with the occupancy API's threads per block).  Every kernel here runs 256-thread
+     * workgroups (4 wavefronts), so the kept schema gets that; what really differs per matrix -- lanes
+     * per row, stage, workgroups, kernel the fast path resolved to -- goes to a second file. */
+    snprintf(file, sizeof file, "%s/spmv_results_hip_block_dim.csv", out_dir);
+    write_block_result_to_csv(name, nz, 256, 256, 256, 256, 256, 256, file);
+    snprintf(file, sizeof file, "%s/spmv_results_hip_launch_shape.csv", out_dir);
+    fp = fopen(file, "a+");
+    if (fp) {
+        fseek(fp, 0, SEEK_END);
+        if (ftell(fp) == 0)
+            fputs("matrix_name,nonzeros,threads_per_workgroup,csr_lanes_per_row_subwave,csr_stream_kernel,"
+                  "csr_stream_workgroups,csr_xwindow_workgroups,csr_xwindow_stage_lines,csr_split_rows,"
+                  "hll_lanes_per_row_subwave,hll_lds_kernel,hll_lds_workgroups,hll_xwindow_workgroups,"
+                  "hll_xwindow_stage_lines\n", fp);
+        fprintf(fp, "%s,%d,256,%d,%s,%d,%d,%d,%d,%d,%s,%d,%d,%d\n", name, nz, ci.lanes_per_row,
+                ci.stream_kernel == 1 ? "csr_stream_local" : (ci.stream_kernel == 2 ? "csr_stream_short" : "csr_stream"),
+                ci.stream_blocks, ci.local_blocks, ci.local_stage_lines, ci.long_rows, hi.lanes_per_row,
+                hi.local_blocks > 0 ? "hll_lds_local" : "hll_lds", hi.stream_blocks, hi.local_blocks,
+                hi.local_stage_lines);
         fclose(fp);
     }
     printf("%-28s M=%d nnz=%d  csr: row %.1f wave %.1f sub %.1f stream %.1f us | hll: row %.1f sub %.1f lds %.1f us"

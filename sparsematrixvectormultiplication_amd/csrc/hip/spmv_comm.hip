@@ -62,6 +62,17 @@ extern "C" int spmv_hip_comm_init(const void *id_bytes, int rank, int nranks) {
     return 0;
 }
 
+// what RCCL itself says about the communicator (not what the caller asked for): bench.py reports it
+extern "C" int spmv_hip_comm_info(int *rank, int *nranks) {
+    if (!g_comm) return fail("comm_info: no communicator");
+    int r = -1, n = -1;
+    NCCL_TRY(ncclCommUserRank(g_comm, &r));
+    NCCL_TRY(ncclCommCount(g_comm, &n));
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    return 0;
+}
+
 extern "C" int spmv_hip_comm_destroy(void) {
     if (g_comm) {
         NCCL_TRY(ncclCommDestroy(g_comm));
@@ -184,44 +195,74 @@ extern "C" int spmv_hip_comm_scatter_staged(const void *d_stage, void *d_y, cons
                           stream ? (hipStream_t)stream : g_stream);
 }
 
+namespace {
+
+// words [lo, hi) of y <- 0xFFFFFFFF (a NaN pattern for fp32 and fp64 alike)
+__global__ __launch_bounds__(kBlock) void poison_words(unsigned *__restrict__ y, long long lo, long long hi) {
+    for (long long k = lo + (long long)blockIdx.x * kBlock + threadIdx.x; k < hi; k += (long long)gridDim.x * kBlock)
+        y[k] = 0xFFFFFFFFu;
+}
+
+// every slice of y this rank does NOT own is overwritten with the poison pattern, so that a gather
+// which delivers nothing (or only part) cannot pass for one that did
+int poison_peer_slices(void *d_y, const int *bounds, int value_bytes, hipStream_t s) {
+    const long long w = value_bytes / 4;
+    const long long own_lo = bounds[g_comm_rank] * w, own_hi = bounds[g_comm_rank + 1] * w, end = bounds[g_comm_size] * w;
+    if (own_lo > 0) hipLaunchKernelGGL(poison_words, dim3(512), dim3(kBlock), 0, s, (unsigned *)d_y, 0LL, own_lo);
+    if (own_hi < end) hipLaunchKernelGGL(poison_words, dim3(512), dim3(kBlock), 0, s, (unsigned *)d_y, own_hi, end);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
 // Time both ways of doing the all-gatherv on THIS node (mean of `iters` after 2 warm-ups, maximum
-// over ranks), check that the second reproduces the first bit for bit, and keep the faster one.
+// over ranks) and keep the faster one that is CORRECT.  Correctness of each mode is established from
+// a poisoned vector: the gathered y the caller hands in is the reference copy; before a mode's check
+// run every slice this rank does not own is overwritten with 0xFF bytes, the mode runs once, and y
+// must equal the reference copy word for word (a mode that delivers nothing leaves poison behind).
+// Mode 0 failing that check is an error; mode 1 failing it is rejected (ms_modes[1] < 0).
 // Collective: every rank must call it with the same bounds.  y must hold a gathered vector already.
 extern "C" int spmv_hip_comm_autotune(void *d_y, const int *bounds, int value_bytes, int iters, int *mode_out,
                                       float *ms_modes) {
     if (need_device()) return -1;
     if (!g_comm) return fail("comm_autotune: no communicator");
     if (!d_y || !bounds || iters <= 0) return fail("comm_autotune: bad arguments");
+    if (value_bytes != 8 && value_bytes != 4) return fail("comm_autotune: value_bytes must be 4 or 8");
     if (g_comm_size > kMaxRanks) return fail("comm_autotune: more than %d ranks", kMaxRanks);
     const size_t bytes = (size_t)bounds[g_comm_size] * value_bytes;
     void *copy = nullptr;
     float *d_ms = nullptr;
-    unsigned long long *d_bad = nullptr;
+    unsigned long long *d_bad = nullptr;  // [2]: mismatching words per mode
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     float ms[2] = {0, 0};
-    unsigned long long bad = 0;
+    unsigned long long bad[2] = {0, 0};
     do {
         hipError_t e = hipMalloc(&copy, std::max<size_t>(bytes, 16));
         if (e == hipSuccess) e = hipMalloc((void **)&d_ms, 2 * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_bad, sizeof *d_bad);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_bad, 2 * sizeof *d_bad);
         if (e == hipSuccess) e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 2 * sizeof *d_bad, g_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(copy, d_y, bytes, hipMemcpyDeviceToDevice, g_stream);  // the reference
         if (e != hipSuccess) { rc = fail("comm_autotune: setup failed: %s", hipGetErrorString(e)); break; }
         for (int mode = 0; mode < 2 && !rc; ++mode) {
+            // correctness from a poisoned vector
+            rc = poison_peer_slices(d_y, bounds, value_bytes, g_stream);
+            if (!rc) rc = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
+            if (rc) break;
+            if (bytes)
+                hipLaunchKernelGGL(count_word_mismatches, dim3(512), dim3(kBlock), 0, g_stream, (const unsigned *)copy,
+                                   (const unsigned *)d_y, (long long)(bytes / 4), d_bad + mode);
+            // whatever the mode did, timing (and the caller afterwards) works on the good vector
+            e = hipMemcpyAsync(d_y, copy, bytes, hipMemcpyDeviceToDevice, g_stream);
             for (int i = 0; i < 2 && !rc; ++i) rc = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
             if (rc) break;
-            if (mode == 0) {  // the reference result
-                e = hipMemcpyAsync(copy, d_y, bytes, hipMemcpyDeviceToDevice, g_stream);
-            } else {          // must be the same words
-                e = hipMemsetAsync(d_bad, 0, sizeof *d_bad, g_stream);
-                if (e == hipSuccess && bytes)
-                    hipLaunchKernelGGL(count_word_mismatches, dim3(512), dim3(kBlock), 0, g_stream,
-                                       (const unsigned *)copy, (const unsigned *)d_y, (long long)(bytes / 4), d_bad);
-            }
             if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
             for (int i = 0; i < iters && !rc && e == hipSuccess; ++i)
                 rc = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
+            if (rc) break;
             if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
             if (e == hipSuccess) e = hipEventElapsedTime(&ms[mode], e0, e1);
@@ -229,16 +270,23 @@ extern "C" int spmv_hip_comm_autotune(void *d_y, const int *bounds, int value_by
             ms[mode] /= (float)iters;
         }
         if (rc) break;
-        // agree across ranks: slowest rank's time per mode, total mismatches
-        e = hipMemcpy(d_ms, ms, sizeof ms, hipMemcpyHostToDevice);
+        // leave y as it was handed in (a rejected mode may have run last)
+        e = hipMemcpyAsync(d_y, copy, bytes, hipMemcpyDeviceToDevice, g_stream);
+        // agree across ranks: slowest rank's time per mode, total mismatches per mode
+        if (e == hipSuccess) e = hipMemcpyAsync(d_ms, ms, sizeof ms, hipMemcpyHostToDevice, g_stream);
         if (e != hipSuccess) { rc = fail("comm_autotune: copy failed: %s", hipGetErrorString(e)); break; }
-        NCCL_TRY(ncclAllReduce(d_ms, d_ms, 2, ncclFloat, ncclMax, g_comm, g_stream));
-        NCCL_TRY(ncclAllReduce(d_bad, d_bad, 1, ncclUint64, ncclSum, g_comm, g_stream));
+        ncclResult_t n = ncclAllReduce(d_ms, d_ms, 2, ncclFloat, ncclMax, g_comm, g_stream);
+        if (n == ncclSuccess) n = ncclAllReduce(d_bad, d_bad, 2, ncclUint64, ncclSum, g_comm, g_stream);
+        if (n != ncclSuccess) { rc = fail("comm_autotune: ncclAllReduce failed: %s", ncclGetErrorString(n)); break; }
         e = hipStreamSynchronize(g_stream);
         if (e == hipSuccess) e = hipMemcpy(ms, d_ms, sizeof ms, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rc = fail("comm_autotune: reduce failed: %s", hipGetErrorString(e)); break; }
-        g_gather_mode = (bad == 0 && ms[1] < ms[0]) ? 1 : 0;
+        if (bad[0]) {
+            rc = fail("comm_autotune: the grouped-broadcast all-gatherv left %llu wrong words in a poisoned y", bad[0]);
+            break;
+        }
+        g_gather_mode = (bad[1] == 0 && ms[1] < ms[0]) ? 1 : 0;
     } while (0);
     (void)hipFree(copy);
     (void)hipFree(d_ms);
@@ -249,7 +297,7 @@ extern "C" int spmv_hip_comm_autotune(void *d_y, const int *bounds, int value_by
     if (mode_out) *mode_out = g_gather_mode;
     if (ms_modes) {
         ms_modes[0] = ms[0];
-        ms_modes[1] = bad ? -1.0f : ms[1];  // negative: mode 1 did not reproduce mode 0 and is not used
+        ms_modes[1] = bad[1] ? -1.0f : ms[1];  // negative: mode 1 did not reproduce the gathered vector and is not used
     }
     return 0;
 }
@@ -442,7 +490,7 @@ void squeeze_ranges(std::vector<std::pair<int, int>> &r, int max_ranges) {
 // The entries of x the handle's rows touch, as at most max_ranges ascending ranges [lo, hi) (128-byte line
 // granularity; small gaps are closed when there are more).  From the x-window plan's line lists; a handle
 // without a plan reports the whole vector.
-extern "C" int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count) {
+static int spmv_hip_csr_needed_ranges_body(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count) {
     if (need_device()) return -1;
     if (!m || !ranges || !count || max_ranges < 1) return fail("csr_needed_ranges: bad arguments");
     std::vector<std::pair<int, int>> r;
@@ -469,6 +517,10 @@ extern "C" int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges,
         ranges[2 * k + 1] = r[k].second;
     }
     return 0;
+}
+
+extern "C" int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count) {
+    return guarded("csr_needed_ranges", [&] { return spmv_hip_csr_needed_ranges_body(m, max_ranges, ranges, count); });
 }
 
 // Pure host logic, the same on every rank: rank q owns entries [bounds[q], bounds[q + 1]); rank p needs
@@ -520,10 +572,12 @@ constexpr int kHaloSegments = 4096;  // segments a rank sends / receives
 
 // Collective: every rank publishes what its handle needs (all-gather of a small fixed-size record), derives
 // its send / receive segments with spmv_hip_halo_plan, and keeps them for spmv_hip_comm_halo_exchange.
-extern "C" int spmv_hip_comm_halo_setup(const spmv_csr_dev *m, const int *bounds) {
+static int spmv_hip_comm_halo_setup_body(const spmv_csr_dev *m, const int *bounds) {
     if (need_device()) return -1;
     if (!g_comm) return fail("comm_halo_setup: no communicator");
     if (!m || !bounds) return fail("comm_halo_setup: NULL argument");
+    // the row bounds double as the ownership of x: only meaningful for square matrices
+    if (m->M_total != m->N) return fail("comm_halo_setup: needs a square matrix (%d x %d)", m->M_total, m->N);
     g_halo_ready = false;
     constexpr int kRecord = 1 + 2 * kHaloRanges;
     std::vector<int> mine(kRecord, 0), all((size_t)kRecord * g_comm_size, 0);
@@ -557,6 +611,10 @@ extern "C" int spmv_hip_comm_halo_setup(const spmv_csr_dev *m, const int *bounds
     } while (0);
     (void)hipFree(d_all);
     return rc;
+}
+
+extern "C" int spmv_hip_comm_halo_setup(const spmv_csr_dev *m, const int *bounds) {
+    return guarded("comm_halo_setup", [&] { return spmv_hip_comm_halo_setup_body(m, bounds); });
 }
 
 // values this rank sends / receives per exchange, and the number of peers it talks to
@@ -624,7 +682,10 @@ int power_iterations_halo(spmv_csr_dev *m, int variant, int iters, double *d_par
         if (csr_launch_any(m, variant, m->x, m->y, g_stream)) return -1;
         hipLaunchKernelGGL((norm2_partial<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)y_own, n, d_part);
         hipLaunchKernelGGL(fold_partials, dim3(1), dim3(kBlock), 0, g_stream, d_part, grid, d_sum);
-        if (g_comm) NCCL_TRY(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, g_comm, g_stream));
+        if (g_comm) {
+            const ncclResult_t n = ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, g_comm, g_stream);
+            if (n != ncclSuccess) return fail("power_iterate_halo: ncclAllReduce failed: %s", ncclGetErrorString(n));
+        }
         hipLaunchKernelGGL(norm_from_sum, dim3(1), dim3(1), 0, g_stream, d_sum, d_norm);
         hipLaunchKernelGGL((scale_into<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)y_own, n, d_norm, x_own);
         if (g_comm && spmv_hip_comm_halo_exchange(m->x, m->value_bytes, g_stream)) return -1;

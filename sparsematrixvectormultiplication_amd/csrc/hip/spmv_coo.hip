@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void coo_split_keys(long long nz, int M, co
 // COO triplets (0-based, any order, file order = tie order) -> a CSR handle, built on the device.
 // Equal to convert_in_csr + spmv_hip_csr_upload except for the order of entries that repeat the same
 // (row, column): the stable sort keeps them in file order, the reference's quicksort does not.
-extern "C" int spmv_hip_csr_from_coo(int M, int N, long long nz, const int *I, const int *J, const double *val,
+static int spmv_hip_csr_from_coo_body(int M, int N, long long nz, const int *I, const int *J, const double *val,
                                      spmv_csr_dev **out) {
     if (need_device()) return -1;
     if (!out) return fail("csr_from_coo: out is NULL");
@@ -109,6 +109,11 @@ extern "C" int spmv_hip_csr_from_coo(int M, int N, long long nz, const int *I, c
     (void)hipFree(d_col);
     (void)hipFree(d_val);
     return rc;
+}
+
+extern "C" int spmv_hip_csr_from_coo(int M, int N, long long nz, const int *I, const int *J, const double *val,
+                                     spmv_csr_dev **out) {
+    return guarded("csr_from_coo", [&] { return spmv_hip_csr_from_coo_body(M, N, nz, I, J, val, out); });
 }
 
 // The CSR arrays of a handle back to the host (tests; hosts that let the device build the matrix):

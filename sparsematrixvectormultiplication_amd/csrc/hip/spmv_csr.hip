@@ -296,16 +296,21 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     m->local_cap = lcap;
     // the ring kernel stages at most kRingRows - 1 rows per block; only worth it when such
     // blocks are still (nearly) full, i.e. rows are not tiny
+    int rows_cap = kStreamRowsCap;
+#ifdef SPMV_EXPERIMENTAL
+    static_assert(kRingRows + 64 <= kRowPtrPad, "row_ptr padding covers the ring kernel's staged segment");
     m->ring_ok = m->stream_cap == kRingCap && Ml > 0 && (double)nz / Ml >= 1.25 * kRingCap / (kRingRows - 1);
-    csr_build_blocks(Ml, rp.data(), m->stream_cap, m->ring_ok ? kRingRows - 1 : kStreamRowsCap, desc,
-                     pieces, long_rows, have_local ? &local.split : nullptr);
+    if (m->ring_ok) rows_cap = kRingRows - 1;
+#endif
+    csr_build_blocks(Ml, rp.data(), m->stream_cap, rows_cap, desc, pieces, long_rows,
+                     have_local ? &local.split : nullptr);
     m->num_blocks = (int)desc.size();
     m->num_long = (int)long_rows.size();
     m->num_partial = (int)pieces.size();
     const int num_partial = m->num_partial;
 
     int rc = 0;
-    rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), (size_t)kRingRows + 64);
+    rc |= upload_array(&m->row_ptr, rp.data(), rp.size(), (size_t)kRowPtrPad);
     if (!rc && have_local && !on_device) {
         rc |= upload_array(&m->ldesc4, local.desc.data(), local.desc.size(), 1);
         if (!rc) rc |= upload_array(&m->ldesc, local.ldesc.data(), local.ldesc.size(), 1);
@@ -364,7 +369,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
 // lists at most kLocalLinesMax strictly ascending lines, every entry's 16-bit slot leads back to
 // its column.  stats (optional, 6 ints): gather blocks, x-window blocks (0 = no plan), listed
 // lines, widest block's lines, long rows, rows handed over because of the line limit.
-extern "C" int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
+static int spmv_hip_csr_plan_check_body(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
                                        int *stats) {
     if (M < 0 || N < 0 || !row_ptr || (value_bytes != 4 && value_bytes != 8)) return fail("plan_check: bad arguments");
     const long long nz = row_ptr[M];
@@ -452,19 +457,24 @@ extern "C" int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const i
     return 0;
 }
 
+extern "C" int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
+                                       int *stats) {
+    return guarded("csr_plan_check", [&] { return spmv_hip_csr_plan_check_body(M, N, row_ptr, col_idx, value_bytes, stats); });
+}
+
 // a whole fp64 matrix whose col / val already sit on the device (spmv_coo.hip)
 int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_val, spmv_csr_dev **out) {
-    return csr_upload_impl<double>(M, N, row_ptr_host, nullptr, nullptr, 0, M, out, d_col, d_val);
+    return guarded("csr_adopt", [&] { return csr_upload_impl<double>(M, N, row_ptr_host, nullptr, nullptr, 0, M, out, d_col, d_val); });
 }
 
 extern "C" int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
                                    const double *values, int row0, int row1, spmv_csr_dev **out) {
-    return csr_upload_impl<double>(M, N, row_ptr, col_idx, values, row0, row1, out);
+    return guarded("csr_upload", [&] { return csr_upload_impl<double>(M, N, row_ptr, col_idx, values, row0, row1, out); });
 }
 
 extern "C" int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx,
                                        const float *values, int row0, int row1, spmv_csr_dev **out) {
-    return csr_upload_impl<float>(M, N, row_ptr, col_idx, values, row0, row1, out);
+    return guarded("csr_upload_f32", [&] { return csr_upload_impl<float>(M, N, row_ptr, col_idx, values, row0, row1, out); });
 }
 
 extern "C" int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **out) {
@@ -614,6 +624,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     else if (m->local_cap == 3072) { if (lnt) SPMV_LOCAL(true, 3072); else SPMV_LOCAL(false, 3072); }
                     else { if (lnt) SPMV_LOCAL(true, 2048); else SPMV_LOCAL(false, 2048); }
 #undef SPMV_LOCAL
+#ifdef SPMV_EXPERIMENTAL
                 } else if (g_stream_kind == 4 && m->ring_ok) {
                     // loader / consumer ring: one persistent 512-thread workgroup per CU
                     const int wgs = std::max(1, std::min(g_num_cus * g_pipe_wgs_per_cu, m->num_blocks));
@@ -655,6 +666,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                         else { if (g_stream_nt) SPMV_WALK(true, 4096, false); else SPMV_WALK(false, 4096, false); }
                     }
 #undef SPMV_WALK
+#endif
                 } else if (cap == 1024) {
                     SPMV_LAUNCH_FLAGS(SPMV_LAUNCH_PROD, 1024, 256);
                 } else if (cap == 3072) {

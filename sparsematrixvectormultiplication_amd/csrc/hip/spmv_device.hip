@@ -138,6 +138,11 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "stream_kind")) {
         if ((value < -1 || value > 5) && (value < 10 || value > 17))
             return fail("set_tuning: stream_kind must be -1..5 (or 10..17 for the ablation probes)");
+#ifndef SPMV_EXPERIMENTAL
+        if (value != -1 && value != 0 && value != 5)
+            return fail("set_tuning: stream_kind %d is an experimental kernel; this library was built without "
+                        "EXPERIMENTAL=1 (make -C csrc EXPERIMENTAL=1)", value);
+#endif
         g_stream_kind = value;
     } else if (!strcmp(key, "gather_mode")) {
         if (value != 0 && value != 1) return fail("set_tuning: gather_mode must be 0 (broadcasts) or 1 (padded all-gather)");

@@ -189,7 +189,7 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
 // Host-only self-check of what HLL upload precomputes (flat slab offsets, workgroup windows, the
 // x-window plan); needs no device.  stats (optional, 4 ints): gather windows, x-window windows
 // (0 = no plan), listed lines, widest window's lines.
-extern "C" int spmv_hip_hll_plan_check(const HLLMatrix *hll, int total_rows, int N, int *stats) {
+static int spmv_hip_hll_plan_check_body(const HLLMatrix *hll, int total_rows, int N, int *stats) {
     if (!hll || total_rows < 0 || N < 0) return fail("hll_plan_check: bad arguments");
     const int H = hll->num_blocks;
     if (H != (total_rows + kHack - 1) / kHack) return fail("hll_plan_check: %d hacks do not match %d rows", H, total_rows);
@@ -253,6 +253,10 @@ extern "C" int spmv_hip_hll_plan_check(const HLLMatrix *hll, int total_rows, int
         stats[3] = widest;
     }
     return 0;
+}
+
+extern "C" int spmv_hip_hll_plan_check(const HLLMatrix *hll, int total_rows, int N, int *stats) {
+    return guarded("hll_plan_check", [&] { return spmv_hip_hll_plan_check_body(hll, total_rows, N, stats); });
 }
 
 namespace {
@@ -347,7 +351,7 @@ int hll_plan_on_device(spmv_hll_dev *m, int total_rows, const std::vector<long l
 // Hacks [hack0, hack1) of the matrix, i.e. rows [32 hack0, min(32 hack1, total_rows)): one
 // rank's share under the reference's hack partitioner (prepare_thread_distribution_hll,
 // src/hll_matrix.c:410-540); y stays full length, the kernels write this handle's rows.
-extern "C" int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
+static int spmv_hip_hll_upload_part_body(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
                                         spmv_hll_dev **out) {
     if (need_device()) return -1;
     if (!hll || !out) return fail("hll_upload: NULL argument");
@@ -412,13 +416,18 @@ extern "C" int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, in
     return 0;
 }
 
+extern "C" int spmv_hip_hll_upload_part(const HLLMatrix *hll, int total_rows, int N, int hack0, int hack1,
+                                        spmv_hll_dev **out) {
+    return guarded("hll_upload", [&] { return spmv_hip_hll_upload_part_body(hll, total_rows, N, hack0, hack1, out); });
+}
+
 extern "C" int spmv_hip_hll_upload(const HLLMatrix *hll, int total_rows, int N, spmv_hll_dev **out) {
     if (!hll) return fail("hll_upload: NULL argument");
     return spmv_hip_hll_upload_part(hll, total_rows, N, 0, hll->num_blocks, out);
 }
 
 // HLL built on the device from a resident CSR matrix (whole matrix, fp64).
-extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out) {
+static int spmv_hip_hll_from_csr_body(const spmv_csr_dev *csr, spmv_hll_dev **out) {
     if (need_device()) return -1;
     if (!csr || !out) return fail("hll_from_csr: NULL argument");
     *out = nullptr;
@@ -486,6 +495,10 @@ extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out
     }
     *out = m;
     return 0;
+}
+
+extern "C" int spmv_hip_hll_from_csr(const spmv_csr_dev *csr, spmv_hll_dev **out) {
+    return guarded("hll_from_csr", [&] { return spmv_hip_hll_from_csr_body(csr, out); });
 }
 
 // flat slab back to the host (tests; hosts that want the HLL arrays): hack_off[hacks + 1],

@@ -15,7 +15,9 @@
 #include <vector>
 
 #include "csr_kernels.hpp"
+#ifdef SPMV_EXPERIMENTAL  // make EXPERIMENTAL=1: the stream variants that lost their A/B + the ablation probes
 #include "csr_kernels_experimental.hpp"
+#endif
 #include "hll_kernels.hpp"
 #include "spmv_hip.h"
 
@@ -62,6 +64,20 @@ int need_device();               // 0, or -1 when spmv_hip_init() has not succee
                         __LINE__);                                                         \
     } while (0)
 
+// The C-ABI never lets a C++ exception cross into the caller: host-side packing uses std::vector,
+// whose allocation failure (a matrix too large for host memory) becomes -1 + message like any other.
+template <typename F>
+int guarded(const char *what, F body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail("%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return fail("%s: %s", what, e.what());
+    }
+}
+
+constexpr int kRowPtrPad = 384;  // entries behind row_ptr (kernels that stage whole row_ptr segments)
 constexpr int kPad = 8192 + 64;  // zero entries behind col/val: the stream / LDS kernels stage
                                    // whole units without bounds tests (>= kStreamCapMax, kHllCap)
 
@@ -171,9 +187,14 @@ template <typename Launch, typename Zero>
 int time_loop(int warmup, int iters, float *ms_each, Launch launch, Zero zero_y) {
     // zero_y() is a no-op when the caller did not ask for the reference's memset
     if (iters <= 0 || !ms_each) return fail("time: iters must be > 0 and ms_each non-NULL");
-    std::vector<hipEvent_t> ev((size_t)iters * 2);
-    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    std::vector<hipEvent_t> ev((size_t)iters * 2, nullptr);
     int rc = 0;
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) rc = fail("time: %s failed: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (auto &e : ev)
+        if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) break;
     for (int i = 0; i < warmup && !rc; ++i) {
         rc = zero_y();
         if (!rc) rc = launch();
@@ -181,15 +202,16 @@ int time_loop(int warmup, int iters, float *ms_each, Launch launch, Zero zero_y)
     for (int i = 0; i < iters && !rc; ++i) {
         rc = zero_y();
         if (rc) break;
-        HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
+        if (!hip_ok(hipEventRecord(ev[2 * i], g_stream), "hipEventRecord")) break;
         rc = launch();
-        HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
+        if (rc) break;
+        if (!hip_ok(hipEventRecord(ev[2 * i + 1], g_stream), "hipEventRecord")) break;
     }
-    if (!rc) {
-        HIP_TRY(hipStreamSynchronize(g_stream));
-        for (int i = 0; i < iters; ++i) HIP_TRY(hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
-    }
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (!rc && hip_ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize"))
+        for (int i = 0; i < iters; ++i)
+            if (!hip_ok(hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]), "hipEventElapsedTime")) break;
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -237,26 +259,33 @@ template <typename Launch>
 int step_loop(void *y, int value_bytes, const int *bounds, int warmup, int iters, float *ms_kernel,
               float *ms_exchange, Launch launch) {
     if (iters <= 0) return fail("step_time: iters must be > 0");
-    std::vector<hipEvent_t> ev((size_t)iters * 3);
-    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    std::vector<hipEvent_t> ev((size_t)iters * 3, nullptr);
     int rc = 0;
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) rc = fail("step_time: %s failed: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (auto &e : ev)
+        if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) break;
     for (int i = -warmup; i < iters && !rc; ++i) {
-        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i], g_stream));
+        if (i >= 0 && !hip_ok(hipEventRecord(ev[3 * i], g_stream), "hipEventRecord")) break;
         rc = launch();
-        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 1], g_stream));
-        if (!rc && g_comm) rc = spmv_hip_comm_allgatherv(y, bounds, value_bytes, g_stream);
-        if (i >= 0) HIP_TRY(hipEventRecord(ev[3 * i + 2], g_stream));
+        if (rc) break;
+        if (i >= 0 && !hip_ok(hipEventRecord(ev[3 * i + 1], g_stream), "hipEventRecord")) break;
+        if (g_comm) rc = spmv_hip_comm_allgatherv(y, bounds, value_bytes, g_stream);
+        if (rc) break;
+        if (i >= 0 && !hip_ok(hipEventRecord(ev[3 * i + 2], g_stream), "hipEventRecord")) break;
     }
-    if (!rc) {
-        HIP_TRY(hipStreamSynchronize(g_stream));
-        for (int i = 0; i < iters; ++i) {
+    if (!rc && hip_ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize")) {
+        for (int i = 0; i < iters && !rc; ++i) {
             float a = 0, b = 0;
-            HIP_TRY(hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
-            HIP_TRY(hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
+            if (!hip_ok(hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]), "hipEventElapsedTime")) break;
+            if (!hip_ok(hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]), "hipEventElapsedTime")) break;
             if (ms_kernel) ms_kernel[i] = a;
             if (ms_exchange) ms_exchange[i] = b;
         }
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
     return rc;
 }

@@ -110,7 +110,15 @@ int coo_group_by_row(int M, int N, size_t nz, const int *I, const int *J, const 
             if (!cursor) {
 #pragma omp atomic write
                 rc = -1;
-            } else {
+            }
+            /* every thread of the team must meet the worksharing loop or none: agree on the
+             * allocation outcome first (first_bad_at is the same for all threads, so the barriers
+             * inside this branch are met by all of them too) */
+#pragma omp barrier
+            int all_ok;
+#pragma omp atomic read
+            all_ok = rc;
+            if (all_ok == 0) {
 #pragma omp for schedule(dynamic, 4)
                 for (int b = 0; b < B; ++b) {
                     const int r0 = b << shift;
@@ -131,8 +139,8 @@ int coo_group_by_row(int M, int N, size_t nz, const int *I, const int *J, const 
                         vals[dst] = tV[e];
                     }
                 }
-                free(cursor);
             }
+            free(cursor);
         }
     }
     if (first_bad_at != (size_t)-1) {

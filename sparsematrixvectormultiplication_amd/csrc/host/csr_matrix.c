@@ -151,7 +151,13 @@ int convert_in_csr(const PreMatrix *pre, CSRMatrix *csr, const char *matrix_name
         if (!scratch || !keep_c || !keep_v) {
 #pragma omp atomic write
             bad_alloc = 1;
-        } else {
+        }
+        /* all threads enter the worksharing loop or none does */
+#pragma omp barrier
+        int any_bad;
+#pragma omp atomic read
+        any_bad = bad_alloc;
+        if (!any_bad) {
 #pragma omp for schedule(dynamic, 2048)
             for (long long r = 0; r < (long long)M; ++r) {
                 const int s = csr->row_ptr[r], len = csr->row_ptr[r + 1] - s;

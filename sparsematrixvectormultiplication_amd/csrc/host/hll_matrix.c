@@ -149,7 +149,13 @@ int convert_to_hll(const PreMatrix *pre, HLLMatrix *hll) {
             if (!my_c || !my_v) {
 #pragma omp atomic write
                 bad_alloc = 1;
-            } else {
+            }
+            /* all threads enter the worksharing loop or none does */
+#pragma omp barrier
+            int any_bad;
+#pragma omp atomic read
+            any_bad = bad_alloc;
+            if (!any_bad) {
 #pragma omp for schedule(dynamic, 2048)
                 for (int r = 0; r < M; ++r) {
                     const int len = row_off[r + 1] - row_off[r];

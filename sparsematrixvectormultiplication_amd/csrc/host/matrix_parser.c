@@ -294,6 +294,7 @@ int read_matrix_market(const char *filename, PreMatrix *mat) {
     {
         const int T = omp_get_max_threads();
         size_t *start = (size_t *)calloc((size_t)T + 1, sizeof(size_t));
+        size_t expanded = 0; /* written by the team itself: the runtime may deliver fewer than T threads */
         if (!start) goto fail;
 #pragma omp parallel num_threads(T)
         {
@@ -306,7 +307,8 @@ int read_matrix_market(const char *filename, PreMatrix *mat) {
 #pragma omp single
             {
                 for (int q = 0; q < nt; ++q) start[q + 1] += start[q];
-                const size_t total = start[nt] ? start[nt] : 1;
+                expanded = start[nt];
+                const size_t total = expanded ? expanded : 1;
                 I = (int *)malloc(total * sizeof(int));
                 J = (int *)malloc(total * sizeof(int));
                 V = (double *)malloc(total * sizeof(double));
@@ -327,7 +329,7 @@ int read_matrix_market(const char *filename, PreMatrix *mat) {
                 }
             }
         }
-        const size_t total = start[T];
+        const size_t total = expanded;
         free(start);
         if (!I || !J || !V) {
             printf("Errore di allocazione memoria\n");

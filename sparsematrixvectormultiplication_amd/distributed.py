@@ -147,6 +147,12 @@ class NativeComm:
         _check(nat.lib().spmv_hip_comm_halo_exchange(C.c_void_p(d_vec), int(value_bytes), C.c_void_p(stream)),
                "spmv_hip_comm_halo_exchange")
 
+    def rccl_ranks(self):
+        """(rank, ranks) as RCCL itself reports them for the communicator."""
+        r, n = C.c_int(-1), C.c_int(-1)
+        _check(nat.lib().spmv_hip_comm_info(C.byref(r), C.byref(n)), "spmv_hip_comm_info")
+        return int(r.value), int(n.value)
+
     def close(self):
         nat.lib().spmv_hip_comm_destroy()
 

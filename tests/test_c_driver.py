@@ -30,6 +30,17 @@ def test_c_driver_runs_reference_protocol_on_golden_matrices(tmp_path, gpu):
             assert float(r["time_warp_csr"]) > 0 and float(r["flops_warp_csr"]) > 0
     roof = list(csv.DictReader(open(out / "spmv_results_hip_roofline.csv")))
     assert len(roof) == len(rows) and all(float(r["rel_err_stream_csr"]) < 1e-10 for r in roof)
+    # launch shapes: the reference's block-size schema (cuda_src/utility.cu:236-261, written at
+    # main_cuda.cu:728) plus what really varies here (lanes per row, stage, workgroups, kernel)
+    dims = list(csv.DictReader(open(out / "spmv_results_hip_block_dim.csv")))
+    assert len(dims) == len(rows)
+    assert list(dims[0]) == ["matrix_name", "nonzeros", "block_size_csr_row", "block_size_csr_warp",
+                             "block_size_csr_shared", "block_size_hll_row", "block_size_hll_warp",
+                             "block_size_hll_shared"]
+    assert all(int(d["block_size_csr_warp"]) % 64 == 0 for d in dims)
+    shapes = list(csv.DictReader(open(out / "spmv_results_hip_launch_shape.csv")))
+    assert len(shapes) == len(rows)
+    assert all(sh["csr_stream_kernel"] in ("csr_stream", "csr_stream_local", "csr_stream_short") for sh in shapes)
     # running again appends, never wipes (the reference deletes the result directory)
     subprocess.run([DRIVER, "--out", str(out), "--iters", "6", os.path.join(GOLDEN, "general_matrix.mtx")],
                    check=True, capture_output=True, timeout=120)
@@ -69,6 +80,19 @@ def test_bench_row_partitioned_two_ranks_sharing_the_gpu(gpu):
     import json
     import socket
     import sys
+    # the driver's own command shape: no outer launcher, bench.py starts its ranks as child processes
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--grid", "24,24,24", "--exchange", "gloo-host", "--check", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), proc.stdout[-2000:]   # ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["rows_per_rank"][0] > 0
+    assert sum(out["config"]["rows_per_rank"]) == out["config"]["rows"]
+    assert proc.stderr.count("check: max|y - y_ref|") == 2
+    # the same through an outer torch.distributed.run, as the task statement's launcher does
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -90,9 +90,9 @@ def test_stream_kernel_block_shapes_repeatable(gpu, oracle, mean, dtype):
         y_ref = oracle.csr_f32_accum64(row_ptr, col, val, x)
     item = np.dtype(dtype).itemsize
     try:
-        for cap, walk, blk in ((2048, 1, 256), (2048, 0, 256), (4096, 1, 256), (4096, 0, 256),
-                               (4096, 0, 512), (8192, 0, 512), (8192, 0, 1024), (2048, 2, 256),
-                               (4096, 2, 256), (2048, 3, 256), (4096, 3, 256), (2048, 4, 256), (2048, 4, 257)):
+        # (the row-walk / pipe / ring variants live behind `make EXPERIMENTAL=1` since round 2)
+        for cap, walk, blk in ((2048, 0, 256), (4096, 0, 256), (4096, 0, 512), (8192, 0, 512), (8192, 0, 1024),
+                               (1024, 0, 256), (3072, 0, 256)):
             set_tuning("stream_cap", cap)
             with sp.CsrDevice(M, N, row_ptr, col, val) as dev:
                 dev.set_x(x)

@@ -9,7 +9,12 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024:
 Infinity-Cache hits are counted by these fabric-side counters, so for a matrix that does
 not fit the 256 MiB cache this is an upper bound on DRAM traffic.
 
-usage: prof_traffic.py <prof dir> <workload name> [kernel-name-substring=short-name ...]
+Every entry is stamped with what it was measured ON -- the sha of the kernels header, the bytes of
+the kernel's own format and its workgroup count, all taken from the JSON line the profiled bench
+printed (trace.log) -- so that bench.py hands it out only for that same kernel revision and plan,
+and `null` for anything else (bench.measured_traffic).
+
+usage: prof_traffic.py <prof dir> <profile tag>
 """
 import csv
 import glob
@@ -18,8 +23,18 @@ import os
 import sys
 from collections import defaultdict
 
-root, workload = sys.argv[1], sys.argv[2]
-names = dict(a.split("=") for a in sys.argv[3:]) or {"csr_stream<": "csr_stream"}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha  # noqa: E402
+
+root, tag = sys.argv[1], sys.argv[2]
+
+
+def bench_line(log):
+    for line in reversed(open(log).read().splitlines()):
+        if line.lstrip().startswith("{") and '"roofline"' in line:
+            return json.loads(line)
+    raise SystemExit(f"no bench JSON line in {log}")
 
 
 def mean_counter(sub, counter):
@@ -31,14 +46,24 @@ def mean_counter(sub, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+line = bench_line(os.path.join(root, "trace.log"))
+kernel = line["roofline"]["kernel"]
+workload = line["config"]["workload_key"]
 fetch = mean_counter("pmc_fetch", "FETCH_SIZE")
 write = mean_counter("pmc_write", "WRITE_SIZE")
-out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+out_path = os.path.join(ROOT, "profiles", "traffic.json")
 table = json.load(open(out_path)) if os.path.exists(out_path) else {}
-for kernel, f in fetch.items():
-    for sub, short in names.items():
-        if sub in kernel:
-            w = write.get(kernel, 0.0)
-            table[f"{short}|{workload}"] = int((2 * f + w) * 1024)
-            print(f"{short}|{workload}: FETCH_SIZE={f:.0f} KiB WRITE_SIZE={w:.0f} KiB -> {(2 * f + w) * 1024 / 1e6:.1f} MB")
+table = {k: v for k, v in table.items() if isinstance(v, dict)}  # round-1 entries carried no stamp
+hits = [k for k in fetch if k.split("(")[0].split("<")[0].strip().endswith(kernel.split("<")[0])]
+if not hits:
+    raise SystemExit(f"kernel {kernel} not found among {sorted(fetch)}")
+for k in hits:
+    f, w = fetch[k], write.get(k, 0.0)
+    table[f"{kernel}|{workload}"] = {
+        "bytes": int((2 * f + w) * 1024), "fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1),
+        "source": tag, "kernel_src_sha": kernel_source_sha(kernel),
+        "format_bytes": int(line["roofline"]["format_bytes_per_launch"]),
+        "blocks": int(line["config"]["workgroups"]),
+        "kernel_ms_mean_unprofiled": line["roofline"]["kernel_ms_mean"]}
+    print(f"{kernel}|{workload}: FETCH_SIZE={f:.0f} KiB WRITE_SIZE={w:.0f} KiB -> {(2 * f + w) * 1024 / 1e6:.1f} MB")
 json.dump(table, open(out_path, "w"), indent=1, sort_keys=True)
