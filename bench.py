@@ -637,13 +637,13 @@ def main():
         # the STREAM variant runs csr_stream_local (x lines staged in LDS, 16-bit local columns)
         # when upload found a plan for the matrix, else csr_stream (gathers)
         from sparsematrixvectormultiplication_amd.device import CSR_STREAM_KERNELS, HLL_LDS_KERNELS
-        stream_name = CSR_STREAM_KERNELS[info["stream_kernel"]] if not hll_mode else None
+        stream_name = CSR_STREAM_KERNELS[info["stream_kernel"]] if not hll_mode else None  # incl. csr_tile
         kernel_name = (HLL_LDS_KERNELS[info["stream_kernel"]] if hll_mode else
                        {0: stream_name, 1: "csr_thread_row", 2: "csr_vector<64,2>", 3: "csr_vector<L,1>",
                         4: stream_name}[variant if variant else info["auto_variant"]])
-        moved = float(per_rank[slow, 5]) if kernel_name.endswith("_local") else float(per_rank[slow, 3])
+        moved = float(per_rank[slow, 5]) if per_rank[slow, 5] > 0 else float(per_rank[slow, 3])
         traffic, traffic_source = (measured_traffic(kernel_name, wl["name"], moved,
-                                                    info["local_blocks"] or info["stream_blocks"])
+                                                    info["local_blocks"] or info.get("tile_blocks", 0) or info["stream_blocks"])
                                    if world == 1 else (None, "PMC passes are taken at N = 1 only"))
         result = {
             "metric": "SpMV GFLOP/s (2*nnz flops / step time); achieved HBM GB/s and % of 8 TB/s alongside",
@@ -656,7 +656,8 @@ def main():
             "config": {"workload": wl["name"] + (" HLL hack=32" if hll_mode else " CSR"),
                        "rows": M, "cols": N, "nnz": nnz_total, "x": "ones",
                        "workload_key": wl["name"],
-                       "kernel": kernel_name, "workgroups": int(info["local_blocks"] or info["stream_blocks"]),
+                       "kernel": kernel_name,
+                       "workgroups": int(info["local_blocks"] or info.get("tile_blocks", 0) or info["stream_blocks"]),
                        "parallelism": f"row-block x{world}" if world > 1 else "1 GPU",
                        "exchange": {"none": "none", "rccl": "RCCL all-gatherv(y), C-ABI communicator, " +
                                     ("one padded ncclAllGather + scatter" if gather_mode == 1 else

@@ -50,7 +50,9 @@ enum {
                                 the x-cache idea is dropped) */
     SPMV_CSR_STREAM = 4      /* nnz-balanced row blocks streamed through LDS: csr_stream_local (x lines of
                                 the block staged in LDS, 16-bit local columns) when upload found an x-window
-                                plan for the matrix, else csr_stream (gathers); what AUTO resolves to */
+                                plan for the matrix; csr_tile (row-block accumulators in LDS, column passes
+                                that keep the gathered band of x in L2, dense passes staged in LDS) for large
+                                matrices with scattered columns; else csr_stream (gathers); what AUTO resolves to */
 };
 
 /* HLL kernel selection.  1..3 answer cuda_src/hll_matrix.cu:346-479. */
@@ -84,7 +86,13 @@ typedef struct {
                               nz (val + 2) + 4 lines + 24 blocks + 4 (M + 1) + val (M + N);
                               0 without a plan (then algo_bytes is what moves)    */
     int stream_kernel;     /* which kernel STREAM / LDS (and AUTO) launches with default tuning:
-                              CSR 0 csr_stream, 1 csr_stream_local, 2 csr_stream_short; HLL 0 hll_lds, 1 hll_lds_local */
+                              CSR 0 csr_stream, 1 csr_stream_local, 2 csr_stream_short, 3 csr_tile;
+                              HLL 0 hll_lds, 1 hll_lds_local */
+    int tile_blocks;       /* CSR: row blocks (workgroups) of csr_tile, 0 = no tile plan */
+    int tile_passes;       /* CSR: column passes over all blocks */
+    int tile_split_rows;   /* CSR: rows beyond the tile limit (split-row kernels, stripe-ordered pieces) */
+    long long tile_entries;        /* CSR: entries held by the tiles */
+    long long tile_staged_entries; /* CSR: ... of which in passes whose x slice is staged in LDS */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -109,10 +117,15 @@ int spmv_hip_flush_cache(size_t bytes);
  *                     line limit), else / otherwise on the host
  *     "local_cap"     0 (auto = 2048) | 1024 | 2048 | 3072   stage of the x-window kernels (3072: +0.5..3 % on the
  *                     nlpkkt-like matrix depending on the box, -8 % on the cant-like one)
+ *     "stream_tile"   -1 (auto) | 0 | 1   build the 2-D tile plan (csr_tile) when the matrix gets no x-window plan;
+ *                     "tile_rows" 0 (auto = 2048) | 256..16384 rows per block, "tile_lmax" (16384) longest row kept in
+ *                     the tiles, "tile_density" (16) columns per entry up to which a pass is staged in LDS, "tile_chunk" 0 (auto)
+ *                     | 2048 | 4096 entries per pass, "tile_balance" 1 | 0 row blocks of equal entry / row counts
  *   read at launch
- *     "stream_kind"   -1 (auto: x-window kernel when the handle has a plan, else csr_stream) | 5 x-window |
- *                     0 csr_stream | 1 row walk | 2 persistent pipe | 3 persistent row walk | 4 loader/consumer
- *                     ring | 10..17 ablation probes (measurement only)
+ *     "stream_kind"   -1 (auto: x-window kernel when the handle has a plan, csr_tile when it has tiles, else
+ *                     csr_stream) | 5 x-window | 6 csr_tile |
+ *                     0 csr_stream; only in a `make EXPERIMENTAL=1` build: 1 row walk | 2 persistent pipe |
+ *                     3 persistent row walk | 4 loader/consumer ring | 10..17 ablation probes (measurement only)
  *     "stream_nt" 0/1, "local_nt" -1 (auto) / 0 / 1   non-temporal hint on the streamed arrays
  *     "stream_xcd"    blocks per XCD run: 0 default (16 for the x-window kernels, dispatch order otherwise),
  *                     -1 one contiguous eighth per XCD, n > 0 runs of n
@@ -141,6 +154,13 @@ int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx
  * stats[6] (optional): gather blocks, x-window blocks (0 = no plan), listed lines, widest block's lines, long
  * rows, rows handed to the split-row kernels because they alone touch too many lines. */
 int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, int *stats);
+/* The same for the csr_tile plan (row blocks x column passes, see spmv_dev_info.tile_*): builds it as upload
+ * would with the given parameters (rows per block: power of two in 256..16384; lmax: longest row kept in the
+ * tiles; density: columns per entry up to which a pass is staged; chunk: 2048 | 4096 entries per pass; balance: 1 = row blocks of about equal entry counts) and replays the kernel's bookkeeping with
+ * integer checksums; needs no device.  stats[6] (optional): row blocks, passes, entries in tiles, entries in
+ * staged passes, rows left to the split-row kernels, widest staged window (columns). */
+int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
+                                 int rows_per_block, int lmax, int density, int chunk, int balance, long long *stats);
 /* COO triplets (0-based, any order) -> a CSR handle, built ON THE DEVICE (upload of the
  * triplets, one stable radix sort by (row, column), row pointers and the x-window plan by kernels).  Same
  * matrix as convert_in_csr + spmv_hip_csr_upload_matrix; entries that repeat one (row, column) keep file

@@ -50,7 +50,9 @@ class DevInfo(C.Structure):
                 ("lanes_per_row", C.c_int), ("stream_blocks", C.c_int), ("long_rows", C.c_int),
                 ("slots", C.c_longlong), ("hacks", C.c_int), ("algo_bytes", C.c_longlong),
                 ("device_bytes", C.c_longlong), ("local_blocks", C.c_int), ("local_stage_lines", C.c_int),
-                ("local_lines", C.c_longlong), ("stream_bytes", C.c_longlong), ("stream_kernel", C.c_int)]
+                ("local_lines", C.c_longlong), ("stream_bytes", C.c_longlong), ("stream_kernel", C.c_int),
+                ("tile_blocks", C.c_int), ("tile_passes", C.c_int), ("tile_split_rows", C.c_int),
+                ("tile_entries", C.c_longlong), ("tile_staged_entries", C.c_longlong)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -187,6 +189,8 @@ _PROTOTYPES = {
                                         C.POINTER(C.c_void_p)]),
     "spmv_hip_csr_download": (C.c_int, [C.c_void_p, c_int_p, c_int_p, C.c_void_p]),
     "spmv_hip_csr_plan_check": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p]),
+    "spmv_hip_csr_tile_plan_check": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
     "spmv_hip_csr_power_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, c_double_p,
                                              c_float_p]),
     "spmv_hip_csr_needed_ranges": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),

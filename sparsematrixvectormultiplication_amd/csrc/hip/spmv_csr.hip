@@ -5,6 +5,7 @@
 #include "spmv_internal.hpp"
 
 #include "plan_kernels.hpp"
+#include "tile_plan.hpp"
 
 // ----------------------------------------------------------- CSR: upload
 namespace {
@@ -42,6 +43,37 @@ void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<i
     }
 }
 
+
+// Pieces of the rows marked in `split` for a tiled handle: cut where the column crosses a stripe of
+// `stripe_cols` columns (and every kLongPiece entries), slots numbered row by row (csr_long_finish adds a
+// row's slots in that order), but the pieces themselves ordered stripe by stripe: the launch then sweeps
+// x one L2-sized stripe at a time instead of gathering from all of it at once.
+void build_striped_pieces(int M, const int *rp, const int *col, const std::vector<unsigned char> &split,
+                          int stripe_cols, std::vector<int4> &pieces, std::vector<int4> &long_rows) {
+    struct Tagged {
+        int stripe;
+        int4 d;
+    };
+    std::vector<Tagged> tmp;
+    long_rows.clear();
+    for (int r = 0; r < M; ++r) {
+        if (!split[r]) continue;
+        const int first_slot = (int)tmp.size();
+        int e = rp[r];
+        const int end = rp[r + 1];
+        while (e < end) {
+            const int s = col[e] / stripe_cols;
+            int f = e + 1;
+            while (f < end && f - e < kLongPiece && col[f] / stripe_cols == s) ++f;
+            tmp.push_back(Tagged{s, int4{r, e, f, (int)tmp.size()}});
+            e = f;
+        }
+        long_rows.push_back(int4{r, first_slot, (int)tmp.size() - first_slot, 0});
+    }
+    std::stable_sort(tmp.begin(), tmp.end(), [](const Tagged &a, const Tagged &b) { return a.stripe < b.stripe; });
+    pieces.resize(tmp.size());
+    for (size_t k = 0; k < tmp.size(); ++k) pieces[k] = tmp[k].d;
+}
 
 bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, int cap, int rows_cap,
                      int line_shift, int lines_max, const std::vector<int4> &baseline, LocalPlan &plan) {
@@ -290,6 +322,72 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
                                      kStreamRowsCap, line_shift, kLocalLinesMax, desc, local);
         if (on_device) local.split.assign((size_t)Ml, 0);
     }
+    // No x-window plan: columns too scattered for 256 lines per block.  Then the 2-D tiles (csr_tile):
+    // row-block accumulators in LDS, the block's entries re-ordered into column passes so that all
+    // workgroups sweep x together (L2-resident band), dense passes staged in LDS.  Needs enough row
+    // blocks to fill the chip; rows longer than tile_lmax stay with the split-row kernels, their
+    // pieces cut at column stripes.
+    TilePlan<T> tiles;
+    bool have_tiles = false, scattered = false;
+    std::vector<int4> tile_pieces, tile_long;
+    if (!have_local && nz > 0 && g_stream_tile != 0 && g_stream_cap == 0) {
+        // Rows per block (auto): two regimes, told apart on a sample of the rows.
+        //  * banded (most entries in passes that can be staged): 32 KiB of accumulators (4096 fp64 / 8192 fp32
+        //    rows), so that two workgroups with their 40 KiB x slices share a CU (road-like, wide band:
+        //    measured best of 2048 / 4096 / 8192);
+        //  * scattered (gather passes): what matters is that a pass spans little of x (the band all blocks
+        //    gather from together must fit L2), that the blocks run in few rounds (a new round starts again at
+        //    column 0) and that not too many of them are on the way at once: the tallest blocks (up to 16384
+        //    rows) that still leave >= 1024 of them, ONE workgroup per CU.  Power-law matrix (fp32, 2^24 rows):
+        //    2.90 ms at 8192 rows, 1.97 ms at 16384 with one workgroup per CU, 2.39 ms with two.
+        const int chunk = g_tile_chunk ? g_tile_chunk : 2048;
+        const bool want = g_stream_tile == 1 || (long long)Ml >= 512LL * 2048;
+        if (want) {
+            std::vector<int> col_copy;
+            std::vector<T> val_copy;
+            const int *hcol = col_idx ? col_idx + e0 : nullptr;
+            const T *hval = values ? values + e0 : nullptr;
+            if (!hcol) {  // adopted arrays live on the device only
+                col_copy.resize((size_t)nz);
+                val_copy.resize((size_t)nz);
+                if (hipMemcpy(col_copy.data(), m->col, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(val_copy.data(), m->val, (size_t)nz * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
+                    drop(m);
+                    return fail("csr_upload: copying the matrix back for the tile plan failed");
+                }
+                hcol = col_copy.data();
+                hval = val_copy.data();
+            }
+            int rb = g_tile_rows;
+            const int density = g_tile_density;
+            if (!rb) {
+                const int banded_rows = 32768 / (int)sizeof(T);
+                // a slice of the matrix from its middle (rows keep their global columns)
+                const int sample = std::min(Ml, 8 * banded_rows), s0 = (Ml - sample) / 2;
+                std::vector<int> srp((size_t)sample + 1);
+                for (int r = 0; r <= sample; ++r) srp[(size_t)r] = rp[(size_t)s0 + r] - rp[(size_t)s0];
+                TilePlan<T> probe;
+                const bool ok = tile_build<T>(sample, N, srp.data(), hcol + rp[(size_t)s0], hval + rp[(size_t)s0], banded_rows,
+                                              g_tile_lmax, density, chunk, g_tile_balance != 0, probe);
+                if (ok && probe.staged_entries * 2 >= probe.entries) {
+                    rb = banded_rows;
+                } else {
+                    rb = 16384;
+                    while (rb > 2048 && (long long)Ml < 1024LL * rb) rb >>= 1;
+                    scattered = true;
+                }
+            }
+            have_tiles = tile_build<T>(Ml, N, rp.data(), hcol, hval, rb, g_tile_lmax, density, chunk, g_tile_balance != 0,
+                                       tiles);
+            // (auto) a matrix made mostly of rows beyond the tile limit gains nothing
+            if (have_tiles && g_stream_tile < 0 && tiles.entries * 2 < nz) have_tiles = false;
+            if (have_tiles) {
+                // stripes of 1 MiB of x: a quarter of an XCD's L2
+                const int stripe_cols = (1 << 20) / (int)sizeof(T);
+                build_striped_pieces(Ml, rp.data(), hcol, tiles.split, stripe_cols, tile_pieces, tile_long);
+            }
+        }
+    }
     // else: larger stages amortise per-workgroup latency on big matrices; small ones need
     // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
     m->stream_cap = have_local ? lcap : (g_stream_cap ? g_stream_cap : (nz >= (16LL << 20) ? 4096 : 2048));
@@ -327,8 +425,33 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
     if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
     if (!rc && num_partial) rc |= upload_array(&m->pieces, pieces.data(), pieces.size(), 0);
-    if (!rc && num_partial) {
-        hipError_t e = hipMalloc(&m->partial, (size_t)num_partial * sizeof(T));
+    if (!rc && have_tiles) {
+        rc |= upload_array(&m->tile_block_pass, tiles.block_pass.data(), tiles.block_pass.size(), 1);
+        if (!rc) rc |= upload_array(&m->tile_block_row, tiles.block_row.data(), tiles.block_row.size(), 1);
+        if (!rc) rc |= upload_array(&m->tile_pass, tiles.pass_desc.data(), tiles.pass_desc.size(), 1);
+        if (!rc) rc |= upload_array(&m->tcol, tiles.tcol.data(), tiles.tcol.size(), 0);
+        if (!rc) rc |= upload_array(&m->tkey, tiles.tkey.data(), tiles.tkey.size(), 0);
+        if (!rc) rc |= upload_array((T **)&m->tval, tiles.tval.data(), tiles.tval.size(), 0);
+        if (!rc && !tile_long.empty()) rc |= upload_array(&m->tile_long_rows, tile_long.data(), tile_long.size(), 0);
+        if (!rc && !tile_pieces.empty()) rc |= upload_array(&m->tile_pieces, tile_pieces.data(), tile_pieces.size(), 0);
+        if (!rc) {
+            m->tile_blocks = tiles.num_blocks;
+            m->tile_rows = tiles.rows_per_block;
+            m->tile_chunk = tiles.chunk;
+            m->tile_lds_min = scattered ? 84 * 1024 : 0;  // more than half a CU's LDS: one workgroup per CU
+            m->tile_passes = (int)tiles.pass_desc.size();
+            m->tile_max_win = tiles.max_win;
+            m->tile_entries = tiles.entries;
+            m->tile_staged = tiles.staged_entries;
+            m->tile_staged_cols = tiles.staged_cols;
+            m->tile_padded = (long long)tiles.tcol.size() - kTileChunkMax;
+            m->tile_num_long = (int)tile_long.size();
+            m->tile_num_pieces = (int)tile_pieces.size();
+        }
+    }
+    const int partial_slots = std::max(num_partial, (int)tile_pieces.size());
+    if (!rc && partial_slots) {
+        hipError_t e = hipMalloc(&m->partial, (size_t)partial_slots * sizeof(T));
         if (e != hipSuccess) rc = fail("hipMalloc(partial) failed: %s", hipGetErrorString(e));
     }
     if (!rc) {
@@ -350,6 +473,9 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     if (have_local)
         m->device_bytes += (size_t)m->local_blocks * 24 + ((size_t)m->local_lines + kLocalLinesMax) * 4 +
                            ((size_t)nz + kPad) * 2;
+    if (have_tiles)
+        m->device_bytes += tiles.tcol.size() * (6 + sizeof(T)) + tiles.pass_desc.size() * 16 + tiles.block_pass.size() * 4 +
+                           (tile_pieces.size() + tile_long.size()) * 16;
 
     // lanes per row for the SUBWAVE kernel: about half the mean row length,
     // rounded to a power of two, so that a typical row takes 1-2 passes
@@ -462,6 +588,133 @@ extern "C" int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const i
     return guarded("csr_plan_check", [&] { return spmv_hip_csr_plan_check_body(M, N, row_ptr, col_idx, value_bytes, stats); });
 }
 
+// Host-only self-check of the csr_tile plan (no device needed): builds the tiles and the stripe-cut pieces
+// exactly as upload does and (1) verifies the structural invariants the kernel relies on (aligned passes
+// within the chunk, ascending rows with a head flag on every row's first entry, staged columns inside the
+// window, passes walking the columns upwards), (2) adds an integer checksum per entry into its row's
+// accumulator and compares every row with the checksum of its entries taken straight from the CSR arrays.  stats (optional, 6 values): blocks,
+// passes, entries in tiles, entries in staged passes, rows left to the split-row kernels, widest window.
+template <typename T>
+static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows_per_block, int lmax, int density,
+                           int chunk, int balance, long long *stats) {
+    const long long nz = rp[M];
+    std::vector<T> val((size_t)nz);
+    for (long long e = 0; e < nz; ++e) val[(size_t)e] = (T)(1 + e % 7);
+    TilePlan<T> plan;
+    if (!tile_build<T>(M, N, rp, col, val.data(), rows_per_block, lmax, density, chunk, balance != 0, plan))
+        return fail("tile_plan_check: the plan does not fit 32-bit entry offsets");
+    const int win_cols = plan.win_cols;
+    auto h = [](long long c, double v) { return (unsigned long long)(c + 1) * 0x9E3779B97F4A7C15ull + (unsigned long long)v; };
+    if ((int)plan.block_pass.size() != plan.num_blocks + 1 || plan.block_pass.back() != (int)plan.pass_desc.size() ||
+        (int)plan.block_row.size() != plan.num_blocks + 1 || plan.block_row[0] != 0 || plan.block_row.back() != M)
+        return fail("tile_plan_check: block / pass tables disagree");
+    long long seen_entries = 0;
+    std::vector<unsigned long long> acc((size_t)rows_per_block);
+    for (int b = 0; b < plan.num_blocks; ++b) {
+        std::fill(acc.begin(), acc.end(), 0ull);
+        const int r0 = plan.block_row[(size_t)b], nrows = plan.block_row[(size_t)b + 1] - r0;
+        if (nrows <= 0 || nrows > rows_per_block) return fail("tile_plan_check: block %d holds %d rows", b, nrows);
+        long long last_max_col = -1;
+        for (int p = plan.block_pass[b]; p < plan.block_pass[b + 1]; ++p) {
+            const int4 d = plan.pass_desc[p];
+            const int count = d.y, wbase = d.z, wlen = d.w;
+            if (count <= 0 || count > chunk || (d.x & 3) || (wbase & 3) || (wlen & 3) || wlen < 0)
+                return fail("tile_plan_check: pass %d is malformed", p);
+            if ((size_t)d.x + (size_t)count > plan.tcol.size() - kTileChunkMax) return fail("tile_plan_check: pass %d leaves the arrays", p);
+            if (wlen && (wlen > win_cols || wbase + wlen > N + 3)) return fail("tile_plan_check: window of pass %d is too wide", p);
+            int prev_row = -1;
+            long long cmin = 1LL << 40, cmax = -1;
+            for (int i = 0; i < count; ++i) {
+                const int c = plan.tcol[(size_t)d.x + i];
+                const unsigned key = plan.tkey[(size_t)d.x + i];
+                const int lrow = (int)(key & kTileRowMask);
+                if ((unsigned)c >= (unsigned)N || lrow >= nrows) return fail("tile_plan_check: entry %d of pass %d is out of range", i, p);
+                if (wlen && (c < wbase || c >= wbase + wlen)) return fail("tile_plan_check: staged pass %d misses column %d", p, c);
+                if (!wlen && c < wbase) return fail("tile_plan_check: pass %d has a column below its base", p);
+                const bool head = (key & kTileHead) != 0;
+                if (head != (lrow != prev_row)) return fail("tile_plan_check: head flag of entry %d in pass %d is wrong", i, p);
+                if (lrow < prev_row) return fail("tile_plan_check: rows of pass %d are not ascending", p);
+                if (key & ~(unsigned)(kTileHead | kTileRowMask)) return fail("tile_plan_check: stray key bits in pass %d", p);
+                prev_row = lrow;
+                cmin = std::min<long long>(cmin, c);
+                cmax = std::max<long long>(cmax, c);
+                // what the kernel does with the entry: every run goes to its row's accumulator exactly once
+                acc[(size_t)lrow] += h(c, (double)plan.tval[(size_t)d.x + i]);
+            }
+            // passes of a block walk the columns upwards (that is what keeps the gathered band in L2)
+            if (cmin < last_max_col) return fail("tile_plan_check: passes of block %d do not ascend in columns", b);
+            last_max_col = cmax;
+            seen_entries += count;
+        }
+        for (int i = 0; i < nrows; ++i) {
+            unsigned long long want = 0;
+            if (!plan.split[(size_t)r0 + i])
+                for (int e = rp[r0 + i]; e < rp[r0 + i + 1]; ++e) want += h(col[e], (double)val[(size_t)e]);
+            if (acc[(size_t)i] != want) return fail("tile_plan_check: row %d does not add up through the tiles", r0 + i);
+        }
+    }
+    if (seen_entries != plan.entries) return fail("tile_plan_check: entry count disagrees");
+    // rows beyond the limit: stripe-cut pieces cover each exactly once, slots row by row
+    std::vector<int4> pieces, long_rows;
+    const int stripe_cols = (1 << 20) / (int)sizeof(T);
+    build_striped_pieces(M, rp, col, plan.split, stripe_cols, pieces, long_rows);
+    std::vector<const int4 *> by_slot(pieces.size(), nullptr);
+    long long split_entries = 0;
+    int last_stripe = -1;
+    for (const int4 &pc : pieces) {
+        if (pc.w < 0 || (size_t)pc.w >= pieces.size() || by_slot[(size_t)pc.w]) return fail("tile_plan_check: piece slots are not a permutation");
+        by_slot[(size_t)pc.w] = &pc;
+        if (pc.z <= pc.y || pc.z - pc.y > kLongPiece) return fail("tile_plan_check: bad piece of row %d", pc.x);
+        const int stripe = col[pc.y] / stripe_cols;
+        if (stripe < last_stripe) return fail("tile_plan_check: pieces are not ordered by stripe");
+        last_stripe = stripe;
+    }
+    int n_split = 0;
+    for (const int4 &l : long_rows) {
+        if (!plan.split[(size_t)l.x]) return fail("tile_plan_check: row %d is split without being long", l.x);
+        int at = rp[l.x];
+        for (int k = 0; k < l.z; ++k) {
+            const int4 *pc = by_slot[(size_t)l.y + k];
+            if (!pc || pc->x != l.x || pc->y != at) return fail("tile_plan_check: pieces of row %d are not contiguous in slot order", l.x);
+            at = pc->z;
+        }
+        if (at != rp[l.x + 1]) return fail("tile_plan_check: pieces of row %d do not cover it", l.x);
+        split_entries += rp[l.x + 1] - rp[l.x];
+        ++n_split;
+    }
+    for (int r = 0; r < M; ++r) n_split -= plan.split[(size_t)r];
+    if (n_split != 0) return fail("tile_plan_check: split rows and piece lists disagree");
+    if (split_entries + plan.entries != nz) return fail("tile_plan_check: tiles + split rows do not hold every entry");
+    if (stats) {
+        stats[0] = plan.num_blocks;
+        stats[1] = (long long)plan.pass_desc.size();
+        stats[2] = plan.entries;
+        stats[3] = plan.staged_entries;
+        stats[4] = (long long)long_rows.size();
+        stats[5] = plan.max_win;
+    }
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
+                                            int rows_per_block, int lmax, int density, int chunk, int balance,
+                                            long long *stats) {
+    if (M < 0 || N < 0 || !row_ptr || (value_bytes != 4 && value_bytes != 8)) return fail("tile_plan_check: bad arguments");
+    if (rows_per_block < 256 || rows_per_block > kTileRowsMax || (rows_per_block & (rows_per_block - 1)) || lmax < 1 ||
+        lmax > 65536 || density < 1 || (chunk != 2048 && chunk != 4096))
+        return fail("tile_plan_check: bad plan parameters");
+    const long long nz = row_ptr[M];
+    if (nz > 0 && !col_idx) return fail("tile_plan_check: col_idx is NULL");
+    for (int r = 0; r < M; ++r)
+        if (row_ptr[r + 1] < row_ptr[r]) return fail("tile_plan_check: row_ptr decreases at row %d", r);
+    for (long long e = 0; e < nz; ++e)
+        if ((unsigned)col_idx[e] >= (unsigned)N) return fail("tile_plan_check: column %d outside [0, %d)", col_idx[e], N);
+    return guarded("tile_plan_check", [&] {
+        return value_bytes == 8 ? tile_plan_check<double>(M, N, row_ptr, col_idx, rows_per_block, lmax, density, chunk, balance, stats)
+                                : tile_plan_check<float>(M, N, row_ptr, col_idx, rows_per_block, lmax, density, chunk, balance, stats);
+    });
+}
+
 // a whole fp64 matrix whose col / val already sit on the device (spmv_coo.hip)
 int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_val, spmv_csr_dev **out) {
     return guarded("csr_adopt", [&] { return csr_upload_impl<double>(M, N, row_ptr_host, nullptr, nullptr, 0, M, out, d_col, d_val); });
@@ -492,6 +745,14 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->ldesc);
     (void)hipFree(m->lines);
     (void)hipFree(m->lcol);
+    (void)hipFree(m->tile_block_pass);
+    (void)hipFree(m->tile_block_row);
+    (void)hipFree(m->tile_pass);
+    (void)hipFree(m->tcol);
+    (void)hipFree(m->tkey);
+    (void)hipFree(m->tval);
+    (void)hipFree(m->tile_long_rows);
+    (void)hipFree(m->tile_pieces);
     (void)hipFree(m->long_rows);
     (void)hipFree(m->pieces);
     (void)hipFree(m->partial);
@@ -520,12 +781,21 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->local_blocks = m->local_blocks;
     out->local_stage_lines = m->local_stage_lines;
     out->local_lines = m->local_lines;
-    out->stream_kernel = m->local_blocks > 0 ? 1
+    out->tile_blocks = m->tile_blocks;
+    out->tile_passes = m->tile_passes;
+    out->tile_entries = m->tile_entries;
+    out->tile_staged_entries = m->tile_staged;
+    out->tile_split_rows = m->tile_num_long;
+    out->stream_kernel = m->local_blocks > 0 ? 1 : m->tile_blocks > 0 ? 3
                          : ((m->stream_cap == 4096 || m->stream_cap == 2048) && m->M_local > 0 &&
                             m->nz < (long long)m->M_local * (m->stream_cap / kBlock)) ? 2 : 0;
     if (m->local_blocks > 0)
         out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
                             4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
+    else if (m->tile_blocks > 0)  // tiles: 4-byte column + 2-byte key + value per (padded) entry; rows beyond the limit as CSR
+        out->stream_bytes = m->tile_padded * (vb + 6) + 16LL * m->tile_passes + 4LL * m->tile_blocks +
+                            (m->nz - m->tile_entries) * (vb + 4) + 16LL * m->tile_num_pieces +
+                            vb * m->M_local + vb * m->N;
     return 0;
 }
 
@@ -607,6 +877,40 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                 // the x-window kernel reads whole aligned lines of x
                 const bool local = (g_stream_kind == -1 || g_stream_kind == 5) && m->local_blocks > 0 &&
                                    ((uintptr_t)x & (kLineBytes - 1)) == 0;
+                const bool tiled = !local && (g_stream_kind == -1 || g_stream_kind == 6) && m->tile_blocks > 0;
+                if (tiled) {
+                    // staging copies 16-byte pieces of x
+                    const int stage_ok = ((uintptr_t)x & 15) == 0;
+                    const size_t lds = std::max((size_t)m->tile_lds_min,
+                                                (size_t)kTileSlotBytes + (size_t)m->tile_rows * sizeof(T) +
+                                                    (stage_ok ? (size_t)m->tile_max_win * sizeof(T) : 0));
+                    const bool tnt = m->nz * (long long)(sizeof(T) + 6) > (128LL << 20);
+                    const int which = (m->tile_chunk == 4096 ? 2 : 0) + (tnt ? 1 : 0);
+                    static size_t lds_allowed[4] = {0, 0, 0, 0};  // per instantiation
+                    const void *fns[4] = {(const void *)csr_tile<T, false, 2048, kTileTrips>, (const void *)csr_tile<T, true, 2048, kTileTrips>,
+                                          (const void *)csr_tile<T, false, 4096, kTileTrips>, (const void *)csr_tile<T, true, 4096, kTileTrips>};
+                    if (lds > lds_allowed[which]) {
+                        HIP_TRY(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        lds_allowed[which] = lds;
+                    }
+#define SPMV_TILE(NT, CH, TRIPS)                                                                                       \
+    hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s, m->tile_blocks,   \
+                       m->tile_rows, stage_ok, g_tile_probe, m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey,         \
+                       (const T *)m->tval, x, y)
+                    if (which == 0) SPMV_TILE(false, 2048, kTileTrips);
+                    else if (which == 1) SPMV_TILE(true, 2048, kTileTrips);
+                    else if (which == 2) SPMV_TILE(false, 4096, kTileTrips);
+                    else SPMV_TILE(true, 4096, kTileTrips);
+#undef SPMV_TILE
+                    if (m->tile_num_long) {  // rows beyond the tile limit: stripe-ordered pieces, slots added row by row
+                        hipLaunchKernelGGL((csr_long_pieces<T, true>), dim3(m->tile_num_pieces), dim3(kBlock), 0, s,
+                                           m->tile_num_pieces, m->tile_pieces, m->col, (const T *)m->val, x, (T *)m->partial);
+                        hipLaunchKernelGGL((csr_long_finish<T>), dim3(m->tile_num_long), dim3(64), 0, s, m->tile_num_long,
+                                           m->tile_long_rows, (const T *)m->partial, y);
+                    }
+                    HIP_TRY(hipGetLastError());
+                    return 0;
+                }
                 if (local) {
                     // runs of 16 neighbouring blocks per XCD: each L2 keeps its own window of x lines
                     // (measured flat from 8 to 128 on three matrices); stream_xcd overrides

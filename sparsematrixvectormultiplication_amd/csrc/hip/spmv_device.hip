@@ -39,6 +39,13 @@ int g_local_cap = 0;
 int g_stream_local = 1;
 int g_plan_on_device = 1;
 int g_stream_kind = -1;
+int g_stream_tile = -1;
+int g_tile_rows = 0;
+int g_tile_lmax = 16384;
+int g_tile_density = 16;
+int g_tile_chunk = 0;
+int g_tile_probe = 0;
+int g_tile_balance = 1;
 int g_pipe_wgs_per_cu = 5;
 int g_num_cus = 256;
 int g_probe_mask = 1023;
@@ -136,14 +143,34 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "probe_mask")) {
         g_probe_mask = value;
     } else if (!strcmp(key, "stream_kind")) {
-        if ((value < -1 || value > 5) && (value < 10 || value > 17))
-            return fail("set_tuning: stream_kind must be -1..5 (or 10..17 for the ablation probes)");
+        if ((value < -1 || value > 6) && (value < 10 || value > 17))
+            return fail("set_tuning: stream_kind must be -1..6 (or 10..17 for the ablation probes)");
 #ifndef SPMV_EXPERIMENTAL
-        if (value != -1 && value != 0 && value != 5)
+        if (value != -1 && value != 0 && value != 5 && value != 6)
             return fail("set_tuning: stream_kind %d is an experimental kernel; this library was built without "
                         "EXPERIMENTAL=1 (make -C csrc EXPERIMENTAL=1)", value);
 #endif
         g_stream_kind = value;
+    } else if (!strcmp(key, "stream_tile")) {
+        if (value < -1 || value > 1) return fail("set_tuning: stream_tile must be -1 (auto), 0 or 1");
+        g_stream_tile = value;
+    } else if (!strcmp(key, "tile_rows")) {
+        if (value != 0 && (value < 256 || value > kTileRowsMax || (value & (value - 1))))
+            return fail("set_tuning: tile_rows must be 0 (auto) or a power of two in 256..%d", kTileRowsMax);
+        g_tile_rows = value;
+    } else if (!strcmp(key, "tile_lmax")) {
+        if (value < 1 || value > 65536) return fail("set_tuning: tile_lmax must be 1..65536");
+        g_tile_lmax = value;
+    } else if (!strcmp(key, "tile_chunk")) {
+        if (value != 0 && value != 2048 && value != 4096) return fail("set_tuning: tile_chunk must be 0 (auto), 2048 or 4096");
+        g_tile_chunk = value;
+    } else if (!strcmp(key, "tile_balance")) {
+        g_tile_balance = value != 0;
+    } else if (!strcmp(key, "tile_probe")) {
+        g_tile_probe = value & 7;
+    } else if (!strcmp(key, "tile_density")) {
+        if (value < 0 || value > 4096) return fail("set_tuning: tile_density must be 0 (never stage) .. 4096");
+        g_tile_density = value;
     } else if (!strcmp(key, "gather_mode")) {
         if (value != 0 && value != 1) return fail("set_tuning: gather_mode must be 0 (broadcasts) or 1 (padded all-gather)");
         g_gather_mode = value;

@@ -19,6 +19,7 @@
 #include "csr_kernels_experimental.hpp"
 #endif
 #include "hll_kernels.hpp"
+#include "tile_kernels.hpp"
 #include "spmv_hip.h"
 
 using namespace spmv;
@@ -42,6 +43,13 @@ extern int g_plan_on_device;  // ... with the device kernels where they apply (0
 extern int g_stream_kind;     // -1 = auto (x-window kernel when the matrix has a plan, else csr_stream), 5 = x-window,
                               // 0 = csr_stream, 1 = row walk, 2 = pipe, 3 = persistent walk, 4 = ring, 10..17 = probes
 extern int g_pipe_wgs_per_cu; // resident workgroups per CU the persistent grids are sized for
+extern int g_stream_tile;     // csr_tile plan at upload: -1 = auto (no x-window plan, enough rows), 0 = never, 1 = whenever no x-window plan
+extern int g_tile_rows;       // rows per block: 0 = auto, else a power of two in 256..8192
+extern int g_tile_lmax;       // rows longer than this stay with the split-row kernels
+extern int g_tile_chunk;      // entries per pass: 0 = auto, 2048 (two workgroups per CU) or 4096 (one)
+extern int g_tile_probe;      // measurement only: bit 0 no LDS staging, bit 1 no gathers, bit 2 no run sums (y is then wrong)
+extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keeps the workgroups in step), 0: equal row counts
+extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
 extern int g_num_cus;
 extern int g_probe_mask;      // csr_probe: table size - 1 (entries) of the folded gather
 
@@ -124,6 +132,23 @@ struct spmv_csr_dev {
     int local_stage_lines = 0;        // LDS stage: most lines any block lists, in steps of 32
     int local_cap = 2048;
     long long local_lines = 0;
+    // csr_tile (2-D tiles: row-block accumulators in LDS x column passes), for matrices without an x-window plan
+    int tile_blocks = 0;              // 0: no tiles
+    int tile_rows = 0;                // rows per block
+    int tile_chunk = 0;               // entries per pass at most (2048 | 4096)
+    int tile_lds_min = 0;             // LDS bytes to ask for at least (scattered matrices: one workgroup per CU)
+    int tile_passes = 0;
+    int tile_max_win = 0;             // widest staged window (columns)
+    long long tile_entries = 0, tile_staged = 0, tile_staged_cols = 0, tile_padded = 0;
+    int *tile_block_row = nullptr;    // [tile_blocks + 1] first row of every block
+    int *tile_block_pass = nullptr;   // [tile_blocks + 1]
+    int4 *tile_pass = nullptr;        // [tile_passes]
+    int *tcol = nullptr;              // [tile_padded + kTileChunkMax]
+    unsigned short *tkey = nullptr;
+    void *tval = nullptr;
+    int4 *tile_long_rows = nullptr;   // rows beyond the tile limit {row, first slot, pieces, 0} ...
+    int4 *tile_pieces = nullptr;      // ... and their pieces, cut at column stripes, stripe by stripe
+    int tile_num_long = 0, tile_num_pieces = 0;
     // heuristics
     int lanes_per_row = 16;
     int auto_variant = SPMV_CSR_STREAM;

@@ -1,0 +1,295 @@
+// tile_kernels.hpp -- csr_tile: CSR SpMV for matrices whose columns are too scattered for the
+// x-window plan of csr_stream_local (road-like graphs, wide random bands, uniformly random and
+// power-law columns: the graph / circuit / economics matrices of the reference's own list,
+// /root/reference/result/result_cuda.csv:2-31).
+//
+// What limits the gather kernels there ("gather wall"): a 64-lane gather costs the
+// texture addresser per DISTINCT LINE (~145 cycles for 64 lines that hit L2), and once x outgrows an
+// XCD's 4 MiB L2 every gathered value drags a whole line across the fabric (~660 cycles).  csr_tile
+// restructures the product in two dimensions instead of one:
+//
+//   * rows are cut into ROW BLOCKS of consecutive rows (at most `rows_per_block`, about equally many
+//     entries each); one workgroup owns a block and keeps its y values as accumulators in LDS for the
+//     whole kernel;
+//   * the block's entries are re-ordered at upload into PASSES = consecutive column ranges of at most
+//     `chunk` (2048 or 4096) entries, and inside a pass by (row, column).  All workgroups start at column 0 and
+//     sweep upwards together, so at any moment the chip gathers from a narrow band of x that stays
+//     in L2 (the L2-sized column stripes of a DCSR scheme, without per-stripe row lists or partial
+//     sums in memory: the accumulators never leave LDS);
+//   * a pass whose column range is narrow and dense enough is STAGED: its slice of x is copied into
+//     LDS with full-width coalesced loads and the per-entry lookups become ds_reads (the x-window
+//     idea with a dense window instead of a line list);
+//   * inside a pass an entry carries a 16-bit key {head flag, local row} and every lane holds FOUR
+//     CONSECUTIVE entries, so most of a row's run is added up in registers: runs that begin and end
+//     inside a lane go straight to the accumulator; a run that crosses lanes is finished by a
+//     right-to-left segmented scan over the lanes' leading partial sums (ds_bpermute inside a
+//     wavefront, one LDS slot per wavefront across them) and added by the lane that holds its head.
+//     One owner per (row, pass), passes in order, a fixed reduction tree: no atomics, the same bits
+//     on every launch.  Rows longer than the plan's limit (16 Ki entries) stay with the split-row
+//     kernels, their pieces cut at L2-sized column stripes and launched stripe by stripe.
+//
+// No reference counterpart (its CUDA kernels gather x per entry, cuda_src/csr_matrix_cuda.cu:122-241).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "csr_kernels.hpp"
+
+namespace spmv {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));  // native vectors: stay in registers where uint4 (a struct) may not
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+constexpr int kTileBlock = 512;      // threads per workgroup (8 wavefronts)
+constexpr int kTileWaves = kTileBlock / 64;
+constexpr int kTileChunkMax = 4096;  // entries per pass at most (the plan's chunk is 2048 or 4096)
+constexpr int kTileRowsMax = 16384;  // rows per block at most (local row fits the key's 14 bits)
+constexpr int kTileHead = 0x8000;    // key bit: first entry of its row in this pass
+constexpr int kTileRowMask = 0x3fff;
+constexpr int kTileTripBytes = kTileBlock * 16;  // x bytes one staging trip of the workgroup copies
+constexpr int kTileTrips = 5;        // trips per pass: windows of up to 40 KiB
+constexpr int kTileAhead = 3;        // passes whose entries are in flight beyond the one being worked on
+constexpr int kTileSlotBytes = 256;  // LDS in front of the accumulators: one (sum, closed) slot per wavefront and quad
+
+template <typename T> struct vec4v;  // four values of a lane's quad
+template <> struct vec4v<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct vec4v<double> { typedef double type __attribute__((ext_vector_type(4))); };
+
+// What a lane holds of one pass while earlier passes are still being worked on: QUADS groups of four
+// consecutive (column, key, value) entries (and, separately, TRIPS 16-byte pieces of a pass's x slice).  Kept
+// as separate arrays of native vectors (not a struct) so that every element lives in its own register
+// whatever the optimiser makes of the rotation of the sets below.
+#define SPMV_TILE_ENTRY_REGS(name) \
+    v4i name##_c[kQuads];          \
+    v2u name##_k[kQuads];          \
+    V4 name##_v[kQuads]
+#define SPMV_TILE_ENTRY_ARGS(name) name##_c, name##_k, name##_v
+
+// Every load of a pass goes out unconditionally -- a full chunk of entries and TRIPS pieces of x, whatever
+// the pass really holds (lanes behind the pass's end re-read its last quad, lanes behind a window's end its
+// last 16 bytes: one line for all of them, no extra traffic) -- so that the NUMBER of loads in flight is a
+// compile-time constant: vmcnt retires in order, and only with a known count can the wait for the current
+// pass's gathers leave the next pass's loads in flight.
+template <typename T, bool NT, int CH>
+__device__ __forceinline__ void tile_issue_entries(v4i (&rc)[CH / (4 * kTileBlock)], v2u (&rk)[CH / (4 * kTileBlock)],
+                                                   typename vec4v<T>::type (&rv)[CH / (4 * kTileBlock)], const int4 d,
+                                                   const int *__restrict__ tcol, const unsigned short *__restrict__ tkey,
+                                                   const T *__restrict__ tval) {
+    using V4 = typename vec4v<T>::type;
+    constexpr int kQuads = CH / (4 * kTileBlock);
+    const int t = threadIdx.x;
+    const int e_last = d.x + ((max(d.y, 1) - 1) & ~3);
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) {
+        const int e = min(d.x + 4 * t + u * 4 * kTileBlock, e_last);
+        rc[u] = stream_load<NT>(reinterpret_cast<const v4i *>(tcol + e));
+        rk[u] = stream_load<NT>(reinterpret_cast<const v2u *>(tkey + e));
+        rv[u] = stream_load<NT>(reinterpret_cast<const V4 *>(tval + e));
+    }
+}
+
+// the pass's slice of x (a gather pass: its first 16 bytes, again and again): 16 bytes per lane and trip
+template <typename T, int TRIPS>
+__device__ __forceinline__ void tile_issue_window(v4u (&rw)[TRIPS], const int4 d, int stage_ok, const T *__restrict__ x) {
+    constexpr int kPer = 16 / (int)sizeof(T);
+    const int t = threadIdx.x;
+    const int wlen = stage_ok ? max(d.w, kPer) : kPer;
+    const char *src = reinterpret_cast<const char *>(x + d.z);
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+        const int j = min((k * kTileBlock + t) * kPer, wlen - kPer);
+        rw[k] = *reinterpret_cast<const v4u *>(src + (size_t)j * sizeof(T));
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T lane_down(T v, int delta) {  // value of lane + delta (own value past lane 63)
+    return __shfl_down(v, delta, 64);
+}
+
+// One pass.  (cc, ck, cv) and cw hold its entries and its x slice; the loads this pass sends out, in this order
+// (vmcnt retires in order, so what is needed soonest goes first): its own gathers, the x slice of the NEXT pass
+// (nw; served by L2), the entries of the pass kTileAhead passes further on (fc, fk, fv; served by HBM, whose
+// latency under load is several passes long).  Past the block's last pass the loads repeat that pass.
+template <typename T, bool NT, int CH, int TRIPS>
+__device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u (&ck)[CH / (4 * kTileBlock)],
+                                          typename vec4v<T>::type (&cv)[CH / (4 * kTileBlock)], v4u (&cw)[TRIPS],
+                                          v4i (&fc)[CH / (4 * kTileBlock)], v2u (&fk)[CH / (4 * kTileBlock)],
+                                          typename vec4v<T>::type (&fv)[CH / (4 * kTileBlock)], v4u (&nw)[TRIPS],
+                                          int p, int p_last, const int4 *__restrict__ pass_desc, int stage_ok,
+                                          int probe, T *acc, T *xs, T *wave_r, int *wave_h,
+                                          const int *__restrict__ tcol, const unsigned short *__restrict__ tkey,
+                                          const T *__restrict__ tval, const T *__restrict__ x) {
+    constexpr int kQuads = CH / (4 * kTileBlock);
+    constexpr int kPer = 16 / (int)sizeof(T);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int4 d = pass_desc[p];
+    const int count = d.y, wbase = d.z;
+    const int wlen = stage_ok ? d.w : 0;
+    if (wlen && !(probe & 1)) {  // (probe bit 0, measurement only: the slice is not written to LDS)
+#pragma unroll
+        for (int k = 0; k < TRIPS; ++k) {
+            const int j = min((k * kTileBlock + t) * kPer, wlen - kPer);  // (the same bytes to the same place)
+            if (k * kTileBlock * kPer < wlen) *reinterpret_cast<v4u *>(xs + j) = cw[k];
+        }
+    }
+    T xv[4 * kQuads];
+    if (!wlen && !(probe & 2)) {  // gathers go out first (vmcnt retires in order): they are back when the barrier opens
+#pragma unroll
+        for (int u = 0; u < kQuads; ++u) {
+            const int i = u * 4 * kTileBlock + 4 * t;
+            // entries behind the pass's end belong to the next pass: masked out, never looked up
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[4 * u + q] = gather(x, i + q < count ? cc[u][q] : wbase);
+        }
+    }
+    // (the last passes re-issue the block's last one: the count in flight stays a constant)
+    tile_issue_window<T, TRIPS>(nw, pass_desc[min(p + 1, p_last)], stage_ok, x);
+    tile_issue_entries<T, NT, CH>(fc, fk, fv, pass_desc[min(p + kTileAhead, p_last)], tcol, tkey, tval);
+    __syncthreads();  // xs is in place; everybody is done with the previous pass's wave slots
+    // ---- a lane's quads: products, the runs that close inside the quad, the open ends
+    T lead[kQuads], tail[kQuads];   // sum before the quad's first head (the whole quad without one) / from its last head on
+    int tail_row[kQuads];           // local row of the run `tail` belongs to (-1: none)
+    bool has_head[kQuads];
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) {
+        const int i = u * 4 * kTileBlock + 4 * t;
+        T cur = T(0);
+        int row = -1;
+        bool seen = false;
+        lead[u] = T(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = i + q < count;
+            const unsigned key = (q & 1 ? ck[u][q >> 1] >> 16 : ck[u][q >> 1]) & 0xffffu;
+            T xq;
+            if (wlen) xq = xs[(in ? cc[u][q] : wbase) - wbase];
+            else xq = (probe & 2) ? T(1) : xv[4 * u + q];
+            const T pr = in ? cv[u][q] * xq : T(0);
+            // an entry behind the pass's end closes whatever run is open and opens nothing
+            if (!in || (key & kTileHead)) {
+                if (!seen) lead[u] = cur;
+                else if (row >= 0 && !(probe & 4)) acc[row] += cur;  // a run inside the quad: this lane owns its row
+                seen = true;
+                cur = pr;
+                row = in ? (int)(key & kTileRowMask) : -1;
+            } else {
+                cur += pr;
+            }
+        }
+        has_head[u] = seen;
+        if (!seen) lead[u] = cur;
+        tail[u] = seen ? cur : T(0);
+        tail_row[u] = seen ? row : -1;
+    }
+    if (probe & 4) return;  // (measurement only: no cross-lane run sums)
+    // ---- runs that cross lanes: right-to-left segmented scan of `lead` over the lanes of a wavefront,
+    // R(s) = lead(s) + (s has a head ? 0 : R(s + 1)): what a run ending in or after lane s collects from s on
+    T chain[kQuads];
+    bool closed[kQuads];
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) {
+        T r = lead[u];
+        int h = has_head[u] ? 1 : 0;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const T rn = lane_down(r, dlt);
+            const int hn = lane_down(h, dlt);
+            if (lane + dlt < 64 && !h) {
+                r += rn;
+                h = hn;
+            }
+        }
+        if (lane == 0) {  // what the previous wavefront's open run collects from this one, and whether it ends here
+            wave_r[u * kTileWaves + wave] = r;
+            wave_h[u * kTileWaves + wave] = h;
+        }
+        // what lane s's tail run collects: the chain starting at lane s + 1
+        chain[u] = lane_down(r, 1);
+        closed[u] = lane_down(h, 1) != 0;
+        if (lane == 63) {
+            chain[u] = T(0);
+            closed[u] = false;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) {
+        if (tail_row[u] >= 0) {
+            T s = chain[u];
+            if (!closed[u]) {  // the run goes on into the following wavefronts (and quads): slot order = entry order
+                for (int w = u * kTileWaves + wave + 1; w < kQuads * kTileWaves; ++w) {
+                    s += wave_r[w];
+                    if (wave_h[w]) break;
+                }
+            }
+            acc[tail_row[u]] += tail[u] + s;
+        }
+    }
+    // no barrier here: the next pass stores xs (last read before the second barrier above) and rewrites the
+    // wave slots only behind its own first barrier, which every lane reaches after this point
+}
+
+// One workgroup per row block; passes software-pipelined: while pass p is multiplied and summed, the x slice of
+// pass p + 1 and the entries of passes p + 1 .. p + 3 are already on their way into registers.
+// pass = {first entry (multiple of 4), entries, first staged column (multiple of 4), staged columns (0: gather)}
+// (second launch bound = wavefronts per SIMD: chunk 2048 is sized for two resident workgroups per CU)
+template <typename T, bool NT, int CH, int TRIPS>
+__global__ __launch_bounds__(kTileBlock, CH == 2048 ? 4 : 2) void csr_tile(int num_blocks, int rows_per_block,
+                                                                          int stage_ok, int probe,
+                                                                          const int *__restrict__ block_row,
+                                                                          const int *__restrict__ block_pass,
+                                                                          const int4 *__restrict__ pass_desc,
+                                                                          const int *__restrict__ tcol,
+                                                                          const unsigned short *__restrict__ tkey,
+                                                                          const T *__restrict__ tval,
+                                                                          const T *__restrict__ x, T *__restrict__ y) {
+    using V4 = typename vec4v<T>::type;
+    constexpr int kQuads = CH / (4 * kTileBlock);  // groups of four consecutive entries a lane holds per pass
+    // LDS: wave slots | acc[rows_per_block] | xs[widest staged window]
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    T *wave_r = reinterpret_cast<T *>(tile_smem);
+    int *wave_h = reinterpret_cast<int *>(wave_r + kQuads * kTileWaves);
+    T *acc = reinterpret_cast<T *>(tile_smem + kTileSlotBytes);
+    T *xs = acc + rows_per_block;
+
+    // workgroup ids go round-robin over the 8 XCDs: give every XCD one contiguous eighth of the row blocks, in
+    // order, so that neighbouring blocks -- whose x slices overlap -- find each other's lines in the same L2
+    const int per_xcd = (num_blocks + 7) >> 3;
+    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || b >= num_blocks) return;
+    const int t = threadIdx.x;
+    const int row0 = block_row[b];
+    const int nrows = block_row[b + 1] - row0;  // <= rows_per_block
+    const int p0 = block_pass[b], p1 = block_pass[b + 1];
+    for (int i = t; i < rows_per_block; i += kTileBlock) acc[i] = T(0);
+    if (p0 < p1) {
+        // entries: four rotating register sets (the current pass + kTileAhead = 3 in flight), x slices: two
+        SPMV_TILE_ENTRY_REGS(e0);
+        SPMV_TILE_ENTRY_REGS(e1);
+        SPMV_TILE_ENTRY_REGS(e2);
+        SPMV_TILE_ENTRY_REGS(e3);
+        v4u wa[TRIPS], wb[TRIPS];
+        const int pl = p1 - 1;
+        tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e0), pass_desc[p0], tcol, tkey, tval);
+        tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e1), pass_desc[min(p0 + 1, pl)], tcol, tkey, tval);
+        tile_issue_window<T, TRIPS>(wa, pass_desc[p0], stage_ok, x);
+        tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e2), pass_desc[min(p0 + 2, pl)], tcol, tkey, tval);
+#define SPMV_TILE_PASS(cur, fill, wcur, wnext, P)                                                                       \
+    tile_pass<T, NT, CH, TRIPS>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), wnext, P, pl, pass_desc,    \
+                                stage_ok, probe, acc, xs, wave_r, wave_h, tcol, tkey, tval, x)
+        for (int p = p0; p < p1; p += 4) {  // wave-uniform
+            SPMV_TILE_PASS(e0, e3, wa, wb, p);
+            if (p + 1 < p1) SPMV_TILE_PASS(e1, e0, wb, wa, p + 1);
+            if (p + 2 < p1) SPMV_TILE_PASS(e2, e1, wa, wb, p + 2);
+            if (p + 3 < p1) SPMV_TILE_PASS(e3, e2, wb, wa, p + 3);
+        }
+#undef SPMV_TILE_PASS
+    }
+    __syncthreads();
+    for (int i = t; i < nrows; i += kTileBlock) y[row0 + i] = acc[i];
+}
+#undef SPMV_TILE_ENTRY_REGS
+#undef SPMV_TILE_ENTRY_ARGS
+
+}  // namespace spmv

@@ -1,0 +1,231 @@
+// tile_plan.hpp -- upload-time builder of the csr_tile format (host code, no device needed: the
+// plan check of tests/ runs it on the CPU).  See tile_kernels.hpp for what the kernel does with it.
+//
+//   rows        cut into blocks of consecutive rows: at most rows_per_block of them (the accumulators' room) and
+//               about equally many entries each (`balance`: a block closes once it holds the mean number of
+//               entries of a full-height block) -- workgroups that take equally long stay in step on their
+//               way up the columns, which is what keeps the band of x they gather from inside L2
+//   long rows   (more than lmax < 2^17 entries) are left out: `split` marks them for the split-row kernels
+//   per block   its entries ordered by column are cut greedily into passes: a pass takes entries while
+//               it has fewer than kTileChunkMax and -- as long as that keeps it dense enough to be worth
+//               staging -- while its column range fits the LDS window; inside a pass entries are
+//               ordered by (row, column) and the first entry of every row carries the head flag
+//   staging     a pass is staged (its slice of x copied to LDS) when its column range fits the window
+//               and holds at least one entry per `density` columns
+#pragma once
+#include <hip/hip_runtime.h>  // int4
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "tile_kernels.hpp"
+
+namespace spmv {
+
+template <typename T>
+struct TilePlan {
+    int rows_per_block = 0;
+    int chunk = 0;                   // entries per pass at most: 2048 or 4096 (the kernel's template parameter)
+    int win_cols = 0;                // widest window a pass may stage
+    int num_blocks = 0;
+    int max_win = 0;                 // widest staged window (columns, multiple of 4)
+    long long entries = 0;           // entries held by the tiles (without padding)
+    long long staged_entries = 0;    // ... of which in staged passes
+    long long staged_cols = 0;       // sum of staged windows (x values copied to LDS per SpMV)
+    std::vector<int> block_row;      // [num_blocks + 1] first row of every block (blocks hold <= rows_per_block rows)
+    std::vector<int> block_pass;     // [num_blocks + 1]
+    std::vector<int4> pass_desc;     // {first entry, entries, window base, window columns (0 = gather)}
+    std::vector<int> tcol;           // [padded entries + kTileChunkMax]
+    std::vector<unsigned short> tkey;
+    std::vector<T> tval;
+    std::vector<unsigned char> split;  // [M] 1: row is not in the tiles (longer than lmax)
+};
+
+namespace tile_detail {
+
+template <typename T>
+struct Part {  // what one builder thread produced for its range of blocks
+    std::vector<int> passes_per_block;
+    std::vector<int4> pass_desc;  // first entry relative to the part
+    std::vector<int> tcol;
+    std::vector<unsigned short> tkey;
+    std::vector<T> tval;
+    long long entries = 0, staged_entries = 0, staged_cols = 0;
+    int max_win = 0;
+};
+
+template <typename T>
+void build_range(int b0, int b1, const int *block_row, const int *rp, const int *col, const T *val, int lmax,
+                 int chunk, int win_cols, int density, Part<T> &out) {
+    std::vector<uint64_t> keyed;  // column << 32 | local row << 17 | position inside the row (rows <= lmax < 2^17)
+    std::vector<uint64_t> pass;
+    for (int b = b0; b < b1; ++b) {
+        const int r0 = block_row[b], r1 = block_row[b + 1];
+        keyed.clear();
+        for (int r = r0; r < r1; ++r) {
+            const int len = rp[r + 1] - rp[r];
+            if (len > lmax) continue;
+            for (int k = 0; k < len; ++k)
+                keyed.push_back(((uint64_t)(unsigned)col[rp[r] + k] << 32) | ((uint64_t)(r - r0) << 17) | (uint64_t)k);
+        }
+        const size_t n = keyed.size();
+        // one pass in CSR order when everything fits: no sort needed to cut, (row, column) is the input order
+        bool sorted_by_col = false;
+        if (n > (size_t)chunk) {
+            std::sort(keyed.begin(), keyed.end());
+            sorted_by_col = true;
+        }
+        int passes = 0;
+        size_t i = 0;
+        while (i < n) {
+            size_t j;
+            if (!sorted_by_col) {
+                j = n;
+            } else {
+                // window-limited cut first: how many entries fall into [base, base + win_cols)?
+                const long long base = (long long)(keyed[i] >> 32) & ~3LL;
+                size_t w = i;
+                const size_t cap = std::min(n, i + (size_t)chunk);
+                while (w < cap && (long long)(keyed[w] >> 32) < base + win_cols) ++w;
+                const long long span = (long long)(keyed[w - 1] >> 32) - base + 1;
+                if ((long long)(w - i) * density >= span) j = w;   // dense enough: a staged pass
+                else j = cap;                                      // sparse here: a full gather pass
+            }
+            pass.assign(keyed.begin() + (long)i, keyed.begin() + (long)j);
+            int cmin = 0x7fffffff, cmax = 0;
+            for (uint64_t k : pass) {
+                const int c = (int)(k >> 32);
+                cmin = std::min(cmin, c);
+                cmax = std::max(cmax, c);
+            }
+            // order inside the pass: (row, position in the row) = (row, column), duplicates in file order
+            if (sorted_by_col)
+                std::sort(pass.begin(), pass.end(),
+                          [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
+            const int count = (int)pass.size();
+            const int wbase = cmin & ~3;
+            int wlen = ((cmax - wbase + 1) + 3) & ~3;
+            const bool staged = wlen <= win_cols && (long long)count * density >= wlen;
+            const int e_first = (int)out.tcol.size();
+            int prev_row = -1;
+            for (uint64_t k : pass) {
+                const int lrow = (int)((k >> 17) & 0x7fff), pos = (int)(k & 0x1ffff);
+                const int e = rp[r0 + lrow] + pos;
+                out.tcol.push_back(col[e]);
+                out.tval.push_back(val[e]);
+                out.tkey.push_back((unsigned short)(lrow | (lrow != prev_row ? kTileHead : 0)));
+                prev_row = lrow;
+            }
+            while (out.tcol.size() & 3) {  // the next pass starts on a multiple of 4
+                out.tcol.push_back(wbase);
+                out.tval.push_back(T(0));
+                out.tkey.push_back(0);
+            }
+            out.pass_desc.push_back(int4{e_first, count, wbase, staged ? wlen : 0});
+            out.entries += count;
+            if (staged) {
+                out.staged_entries += count;
+                out.staged_cols += wlen;
+                out.max_win = std::max(out.max_win, wlen);
+            }
+            ++passes;
+            i = j;
+        }
+        out.passes_per_block.push_back(passes);
+    }
+}
+
+}  // namespace tile_detail
+
+// false: the tiles would not hold the matrix (entry offsets beyond 32 bits)
+template <typename T>
+bool tile_build(int M, int N, const int *rp, const int *col, const T *val, int rows_per_block, int lmax, int density,
+                int chunk, bool balance, TilePlan<T> &plan) {
+    (void)N;
+    // the window a pass may stage: kTileTrips trips of the workgroup = 40 KiB, which with a 2048-entry chunk and
+    // 2048 fp64 accumulators lets two workgroups share a CU's LDS, and with 8192 of them still fits one
+    const int win_cols = kTileTrips * kTileTripBytes / (int)sizeof(T);
+    plan = TilePlan<T>();
+    plan.rows_per_block = rows_per_block;
+    plan.chunk = chunk;
+    plan.win_cols = win_cols;
+    plan.split.assign((size_t)M, 0);
+    long long in_tiles = 0;
+    for (int r = 0; r < M; ++r) {
+        plan.split[r] = rp[r + 1] - rp[r] > lmax;
+        if (!plan.split[r]) in_tiles += rp[r + 1] - rp[r];
+    }
+    // block boundaries: the row cap, and (balance) the mean entry count of a full-height block
+    const long long full_blocks = std::max(1, (M + rows_per_block - 1) / rows_per_block);
+    const long long target = balance ? std::max<long long>(chunk, (in_tiles + full_blocks - 1) / full_blocks) : (1LL << 62);
+    plan.block_row.assign(1, 0);
+    {
+        long long held = 0;
+        for (int r = 0; r < M; ++r) {
+            const int len = plan.split[r] ? 0 : rp[r + 1] - rp[r];
+            if (r - plan.block_row.back() == rows_per_block || (held >= target && r > plan.block_row.back())) {
+                plan.block_row.push_back(r);
+                held = 0;
+            }
+            held += len;
+        }
+        if (M > 0) plan.block_row.push_back(M);
+    }
+    plan.num_blocks = (int)plan.block_row.size() - 1;
+    const int B = plan.num_blocks;
+    int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    threads = std::max(1, std::min(threads, B / 4));
+    std::vector<tile_detail::Part<T>> parts((size_t)threads);
+    // blocks are dealt out in contiguous ranges balanced by entries
+    std::vector<int> cut((size_t)threads + 1, B);
+    cut[0] = 0;
+    {
+        const long long total = rp[M];
+        int th = 1;
+        for (int b = 0; b < B && th < threads; ++b)
+            if ((long long)rp[plan.block_row[(size_t)b + 1]] * threads >= total * th) cut[th++] = b + 1;
+    }
+    std::vector<std::thread> pool;
+    for (int th = 0; th < threads; ++th)
+        pool.emplace_back([&, th] {
+            tile_detail::build_range<T>(cut[th], cut[th + 1], plan.block_row.data(), rp, col, val, lmax, chunk, win_cols,
+                                        density, parts[th]);
+        });
+    for (auto &th : pool) th.join();
+    size_t total_entries = 0, total_passes = 0;
+    for (const auto &p : parts) {
+        total_entries += p.tcol.size();
+        total_passes += p.pass_desc.size();
+    }
+    if (total_entries + kTileChunkMax >= 0x7fffffffull) return false;
+    plan.tcol.reserve(total_entries + kTileChunkMax);
+    plan.tkey.reserve(total_entries + kTileChunkMax);
+    plan.tval.reserve(total_entries + kTileChunkMax);
+    plan.pass_desc.reserve(total_passes);
+    plan.block_pass.assign(1, 0);
+    for (const auto &p : parts) {
+        const int base = (int)plan.tcol.size();
+        for (int4 d : p.pass_desc) {
+            d.x += base;
+            plan.pass_desc.push_back(d);
+        }
+        for (int n : p.passes_per_block) plan.block_pass.push_back(plan.block_pass.back() + n);
+        plan.tcol.insert(plan.tcol.end(), p.tcol.begin(), p.tcol.end());
+        plan.tkey.insert(plan.tkey.end(), p.tkey.begin(), p.tkey.end());
+        plan.tval.insert(plan.tval.end(), p.tval.begin(), p.tval.end());
+        plan.entries += p.entries;
+        plan.staged_entries += p.staged_entries;
+        plan.staged_cols += p.staged_cols;
+        plan.max_win = std::max(plan.max_win, p.max_win);
+    }
+    // the kernel loads whole units past a pass's end
+    plan.tcol.insert(plan.tcol.end(), (size_t)kTileChunkMax, 0);
+    plan.tkey.insert(plan.tkey.end(), (size_t)kTileChunkMax, 0);
+    plan.tval.insert(plan.tval.end(), (size_t)kTileChunkMax, T(0));
+    return true;
+}
+
+}  // namespace spmv

@@ -1,0 +1,173 @@
+"""GPU parity of csr_tile (2-D tiles: row-block accumulators in LDS x column passes, dense passes staged in
+LDS, split-row kernels with stripe-ordered pieces for the longest rows) against the oracle, through the C-ABI.
+fp64 gate 1e-10 (norm-wise and row-wise, tests/_util.py); fp32 1e-5 norm-wise against the fp64-accumulated
+oracle loop (no reference counterpart for fp32: pinned by this repo's oracle only)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import sparsematrixvectormultiplication_amd as sp
+from _util import FP32_NORMWISE_RTOL, assert_parity
+from conftest import GOLDEN_CASES, golden_path, load_golden
+from sparsematrixvectormultiplication_amd.device import set_tuning
+
+pytestmark = pytest.mark.gpu
+
+
+def scattered(rng, M, N, mean, sigma=None, dtype=np.float64, lens=None):
+    lens = rng.poisson(mean, M).astype(np.int64) if lens is None else np.asarray(lens, dtype=np.int64)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(M), lens)
+    if sigma is None:
+        col = rng.integers(0, N, rp[-1])
+    else:
+        col = np.clip(rows * (N - 1) // max(M - 1, 1) + np.rint(rng.normal(0, sigma, rp[-1])).astype(np.int64), 0, N - 1)
+    order = np.lexsort((col, rows))
+    return rp, col[order].astype(np.int32), rng.uniform(-1, 1, rp[-1]).astype(dtype)
+
+
+class tuned:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            set_tuning(k, v)
+
+    def __exit__(self, *exc):
+        defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 16384, "tile_density": 16, "stream_kind": -1,
+                    "tile_balance": 1, "tile_chunk": 0}
+        for k in self.kv:
+            set_tuning(k, defaults[k])
+
+
+def check(dev, x, y_ref, rp, col, val, dtype, what):
+    item = np.dtype(dtype).itemsize
+    first = None
+    for rep in range(3):
+        sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, len(y_ref) * item)  # every row must be written
+        dev.set_x(x)
+        dev.run(sp.CSR_STREAM)
+        y = dev.get_y()
+        if dtype == np.float64:
+            assert_parity(y, y_ref, rp, col, val, x, what=f"{what} rep={rep}")
+        else:
+            assert np.all(np.isfinite(y))
+            err = np.max(np.abs(y.astype(np.float64) - y_ref)) / max(np.max(np.abs(y_ref)), 1e-300)
+            assert err <= FP32_NORMWISE_RTOL, f"{what}: {err:.3e}"
+        first = y if first is None else first
+        assert y.tobytes() == first.tobytes(), f"{what}: result changed between launches"
+    return first
+
+
+def reference(oracle, rp, col, val, x, dtype):
+    return oracle.csr_serial(rp, col, val, x) if dtype == np.float64 else oracle.csr_f32_accum64(rp, col, val, x)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("rows", [256, 1024])
+def test_tile_kernel_gather_passes_uniform_columns(gpu, oracle, dtype, rows):
+    rng = np.random.default_rng(5)
+    M, N = 7001, 2_000_003
+    rp, col, val = scattered(rng, M, N, 18, dtype=dtype)
+    x = rng.uniform(-1, 1, N).astype(dtype)
+    y_ref = reference(oracle, rp, col, val, x, dtype)
+    with tuned(stream_tile=1, tile_rows=rows):
+        with sp.CsrDevice(M, N, rp, col, val) as dev:
+            info = dev.info()
+            assert info["stream_kernel"] == 3 and info["tile_blocks"] >= (M + rows - 1) // rows
+            assert info["tile_entries"] == rp[-1] and info["tile_staged_entries"] == 0
+            if rows == 1024:
+                assert info["tile_passes"] > info["tile_blocks"]   # several column passes per block
+            y = check(dev, x, y_ref, rp, col, val, dtype, f"uniform rows={rows}")
+            # the gather kernel on the same handle agrees within the gate too
+            with tuned(stream_kind=0):
+                y0 = dev.spmv(x, sp.CSR_STREAM)
+            scale = np.max(np.abs(y_ref))
+            assert np.max(np.abs(y.astype(np.float64) - y0)) <= (1e-10 if dtype == np.float64 else 1e-5) * scale
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mean,sigma", [(3, 1500), (30, 9000), (12, 200)])
+def test_tile_kernel_staged_passes_banded_columns(gpu, oracle, dtype, mean, sigma):
+    rng = np.random.default_rng(mean)
+    M = N = 40_000
+    rp, col, val = scattered(rng, M, N, mean, sigma=sigma, dtype=dtype)
+    x = rng.uniform(-1, 1, N).astype(dtype)
+    y_ref = reference(oracle, rp, col, val, x, dtype)
+    with tuned(stream_tile=1, tile_rows=2048):
+        with sp.CsrDevice(M, N, rp, col, val) as dev:
+            info = dev.info()
+            if info["local_blocks"]:
+                pytest.skip("narrow enough for the x-window plan")
+            assert info["stream_kernel"] == 3 and info["tile_staged_entries"] > 0.5 * info["tile_entries"]
+            check(dev, x, y_ref, rp, col, val, dtype, f"band mean={mean} sigma={sigma}")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tile_kernel_skewed_rows_sub_runs_and_split_rows(gpu, oracle, dtype):
+    """Power-law row lengths: runs longer than one lane's share (sub-runs + multi heads), rows beyond the tile
+    limit (split-row kernels, pieces cut at column stripes), empty rows, a last block that is not full."""
+    rng = np.random.default_rng(9)
+    M, N = 6500, 3_000_000
+    lens = np.minimum((1.08 / rng.random(M)).astype(np.int64), 60000)
+    lens[rng.random(M) < 0.1] = 0
+    lens[[11, 3000, 6499]] = [50000, 5000, 900]
+    rp, col, val = scattered(rng, M, N, 0, dtype=dtype, lens=lens)
+    x = rng.uniform(-1, 1, N).astype(dtype)
+    y_ref = reference(oracle, rp, col, val, x, dtype)
+    for lmax, balance in ((16384, 1), (700, 1), (700, 0), (40, 1)):
+        with tuned(stream_tile=1, tile_rows=512, tile_lmax=lmax, tile_balance=balance):
+            with sp.CsrDevice(M, N, rp, col, val) as dev:
+                info = dev.info()
+                assert info["stream_kernel"] == 3 and info["tile_split_rows"] == int((lens > lmax).sum()) > 0
+                assert info["tile_entries"] == int(lens[lens <= lmax].sum())
+                check(dev, x, y_ref, rp, col, val, dtype, f"skewed lmax={lmax} balance={balance}")
+
+
+def test_tile_kernel_row_block_handle_and_foreign_x(gpu, oracle):
+    """A row block keeps global columns and writes its rows of the full y; run_on with a 16-byte aligned x
+    stages, with a misaligned x it gathers (same result within the gate)."""
+    rng = np.random.default_rng(3)
+    M = N = 30_000
+    rp, col, val = scattered(rng, M, N, 14, sigma=2500)
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_serial(rp, col, val, x)
+    L = sp.lib()
+    with tuned(stream_tile=1, tile_rows=1024):
+        with sp.CsrDevice(M, N, rp, col, val, row0=5000, row1=27001) as part:
+            assert part.info()["stream_kernel"] == 3
+            y = part.spmv(x, sp.CSR_STREAM)
+            assert_parity(y[5000:27001], y_ref[5000:27001], rp[5000:27002] - rp[5000], col[rp[5000]:rp[27001]],
+                          val[rp[5000]:rp[27001]], x, what="tile row block")
+        with sp.CsrDevice(M, N, rp, col, val) as dev:
+            assert dev.info()["tile_staged_entries"] > 0
+            buf, ybuf = C.c_void_p(), C.c_void_p()
+            assert L.spmv_hip_malloc(C.byref(buf), (N + 64) * 8) == 0 and L.spmv_hip_malloc(C.byref(ybuf), M * 8) == 0
+            try:
+                for shift in (0, 8, 16):
+                    xp = C.c_void_p(buf.value + shift)
+                    assert L.spmv_hip_memcpy_h2d(xp, x.ctypes.data_as(C.c_void_p), N * 8) == 0
+                    assert L.spmv_hip_memset(ybuf, 0xFF, M * 8) == 0
+                    assert L.spmv_hip_csr_run_on(dev.h, sp.CSR_STREAM, xp, ybuf, None) == 0
+                    y = np.empty(M)
+                    assert L.spmv_hip_memcpy_d2h(y.ctypes.data_as(C.c_void_p), ybuf, M * 8) == 0
+                    assert_parity(y, y_ref, rp, col, val, x, what=f"tile run_on shift={shift}")
+            finally:
+                L.spmv_hip_free(buf)
+                L.spmv_hip_free(ybuf)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_tile_kernel_on_reference_golden(gpu, name):
+    """The reference's own fixtures through the tile kernel (forced; tiny matrices: one block)."""
+    g = load_golden(name)
+    csr = sp.convert_in_csr(sp.read_matrix_market(golden_path(name)))
+    with tuned(stream_tile=1, tile_rows=256, tile_lmax=100):
+        with sp.CsrDevice.from_host(csr) as dev:
+            if csr.nz and not dev.info()["local_blocks"]:
+                assert dev.info()["stream_kernel"] == 3
+            for x, key in ((np.ones(csr.N), "y_ones"), (g["x_rand"], "y_rand")):
+                assert_parity(dev.spmv(x, sp.CSR_STREAM), g[key], csr.row_ptr, csr.col_idx, csr.values, x,
+                              what=f"{name}/{key}/tile")

@@ -114,3 +114,61 @@ def test_halo_plan_is_consistent_between_ranks():
                 want[lo:hi] = 1
             want[bounds[r]:bounds[r + 1]] = 0
             assert np.array_equal(got, want), (ranks, r)
+
+
+# ---------------------------------------------------------------- csr_tile plan (2-D tiles)
+def _scattered(rng, M, N, mean, sigma=None):
+    """rows of ~mean entries, columns uniform over N (sigma None) or gaussian around the diagonal"""
+    lens = rng.poisson(mean, M).astype(np.int64)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(M), lens)
+    if sigma is None:
+        col = rng.integers(0, N, rp[-1])
+    else:
+        col = np.clip(rows * (N - 1) // max(M - 1, 1) + np.rint(rng.normal(0, sigma, rp[-1])).astype(np.int64), 0, N - 1)
+    order = np.lexsort((col, rows))     # ascending columns inside each row, repeats allowed
+    return rp, col[order].astype(np.int32)
+
+
+@pytest.mark.parametrize("vb", [8, 4])
+@pytest.mark.parametrize("rows_per_block,chunk", [(256, 2048), (2048, 2048), (2048, 4096)])
+def test_tile_plan_on_scattered_banded_and_skewed_matrices(vb, rows_per_block, chunk):
+    import functools
+    real = sp.csr_tile_plan_check
+    sp_check = functools.partial(real, chunk=chunk)
+    rng = np.random.default_rng(77 + vb)
+    # uniformly random columns: every block needs several gather passes
+    rp, col = _scattered(rng, 9000, 3_000_000, 20)
+    st = sp_check(9000, 3_000_000, rp, col, vb, rows_per_block)
+    assert st["entries"] == rp[-1] and st["split_rows"] == 0 and st["passes"] >= st["blocks"]
+    if rows_per_block == 2048:
+        assert st["passes"] > 2 * st["blocks"] and st["staged_entries"] == 0
+    # a band: passes get staged in LDS
+    rp, col = _scattered(rng, 9000, 9000, 12, sigma=300)
+    st = sp_check(9000, 9000, rp, col, vb, rows_per_block)
+    assert st["staged_entries"] > 0.9 * st["entries"] and 0 < st["max_window"] <= 40960 // vb
+    # skewed row lengths: runs longer than a lane's share (sub-runs), rows beyond the limit (split)
+    lens = np.minimum((1.08 / rng.random(5000)).astype(np.int64), 40000)
+    lens[[7, 4100]] = [30000, 70]
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.integers(0, 600_000, n)) for n in lens]).astype(np.int32)
+    st = sp_check(5000, 600_000, rp, col, vb, rows_per_block, lmax=5000)
+    assert st["split_rows"] == int((lens > 5000).sum()) >= 1
+    assert st["entries"] == int(lens[lens <= 5000].sum())
+    # every row beyond a tiny limit is split; empty matrix; one row
+    st = sp_check(5000, 600_000, rp, col, vb, rows_per_block, lmax=1)
+    assert st["entries"] == int((lens == 1).sum())
+    # equal-work blocks: more of them than ceil(M / rows), never fewer; equal-height blocks on request
+    stb = sp_check(5000, 600_000, rp, col, vb, rows_per_block, lmax=5000)
+    stn = sp_check(5000, 600_000, rp, col, vb, rows_per_block, lmax=5000, balance=False)
+    assert stn["blocks"] == -(-5000 // rows_per_block) <= stb["blocks"] and stb["entries"] == stn["entries"]
+    assert sp_check(0, 5, np.zeros(1, np.int32), np.zeros(0, np.int32), vb, rows_per_block)["blocks"] == 0
+    st = sp_check(1, 5, np.array([0, 3], np.int32), np.array([4, 0, 4], np.int32), vb, rows_per_block)
+    assert st["blocks"] == 1 and st["entries"] == 3
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_tile_plan_on_golden_matrices(name):
+    csr = sp.convert_in_csr(sp.read_matrix_market(golden_path(name)))
+    st = sp.csr_tile_plan_check(csr.M, csr.N, csr.row_ptr, csr.col_idx, 8, 256, lmax=64)
+    assert st["entries"] + 0 <= csr.nz
