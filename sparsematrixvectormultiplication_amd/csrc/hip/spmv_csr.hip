@@ -338,7 +338,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
         //  * scattered (gather passes): what matters is that a pass spans little of x (the band all blocks
         //    gather from together must fit L2), that the blocks run in few rounds (a new round starts again at
         //    column 0) and that not too many of them are on the way at once: the tallest blocks (up to 16384
-        //    rows) that still leave >= 1024 of them, ONE workgroup per CU.  Power-law matrix (fp32, 2^24 rows):
+        //    rows) that still leave ~2 per CU, ONE workgroup per CU.  Power-law matrix (fp32, 2^24 rows):
         //    2.90 ms at 8192 rows, 1.97 ms at 16384 with one workgroup per CU, 2.39 ms with two.
         const int chunk = g_tile_chunk ? g_tile_chunk : 2048;
         const bool want = g_stream_tile == 1 || (long long)Ml >= 512LL * 2048;
@@ -373,7 +373,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
                     rb = banded_rows;
                 } else {
                     rb = 16384;
-                    while (rb > 2048 && (long long)Ml < 1024LL * rb) rb >>= 1;
+                    while (rb > 2048 && (long long)Ml < 448LL * rb) rb >>= 1;  // at least ~1.75 blocks per CU
                     scattered = true;
                 }
             }

@@ -92,6 +92,6 @@ for name, make in zoo:
             hms = h.time(sp.HLL_AUTO, 3, 20, zero_y=False)
     gb = info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9
     hgb = hi_info["algo_bytes"] / (hms.mean() * 1e-3) / 1e9
-    print(f"| {name} | {M} | {info['nz']} | {('csr_stream', 'csr_stream_local', 'csr_stream_short')[info['stream_kernel']]} | "
+    print(f"| {name} | {M} | {info['nz']} | {sp.device.CSR_STREAM_KERNELS[info['stream_kernel']]} | "
           f"{ms.mean() * 1e3:.1f} | {gb:.0f} | {gb / 80:.1f} | {'hll_lds_local' if hi_info['local_blocks'] else 'hll_lds'} | "
           f"{hms.mean() * 1e3:.1f} | {hgb / 80:.1f} | ok |", flush=True)
