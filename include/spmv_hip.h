@@ -296,10 +296,23 @@ int spmv_hip_csr_power_iterate(spmv_csr_dev *m, int variant, int iters, const in
  *   spmv_hip_comm_halo_info      values sent / received per exchange, peers talked to
  *   spmv_hip_csr_power_iterate_halo   the power iteration with that exchange: partial norms + one all-reduce,
  *                                every rank scales its own range of x, halo segments of x travel */
+/* N4, overlap of the exchange with the product.  A rank's x-window blocks are split into INTERIOR blocks (every
+ * x line they list lies in the rank's own range [row0, row0 + M_local) of x: they can run before the halo has
+ * arrived) and BOUNDARY blocks (the rest, plus rows outside the plan).
+ *   spmv_hip_csr_split_interior   computes the split from the handle's plan (spmv_hip_comm_halo_setup calls it);
+ *                                 counts[4] (optional): interior blocks, boundary blocks, entries in interior
+ *                                 blocks, entries elsewhere.  A handle without an x-window plan has no interior.
+ *   spmv_hip_csr_run_part         part 0 = interior blocks only, part 1 = everything else; 0 then 1 = one
+ *                                 spmv_hip_csr_run_on(STREAM), bit for bit (d_x / d_y / stream NULL = the handle's)
+ *   spmv_hip_csr_power_iterate_halo   uses it when a communicator exists: the halo exchange runs on a second
+ *                                 stream beside the interior blocks, the boundary blocks wait for its event
+ *                                 ("halo_overlap" tuning knob 1 | 0) */
+int spmv_hip_csr_split_interior(spmv_csr_dev *m, long long *counts);
+int spmv_hip_csr_run_part(spmv_csr_dev *m, int part, const void *d_x, void *d_y, void *stream);
 int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count);
 int spmv_hip_halo_plan(int ranks, int rank, const int *bounds, const int *counts, const int *ranges, int stride,
                        int max_segments, int *send, int *nsend, int *recv, int *nrecv);
-int spmv_hip_comm_halo_setup(const spmv_csr_dev *m, const int *bounds);
+int spmv_hip_comm_halo_setup(spmv_csr_dev *m, const int *bounds);
 int spmv_hip_comm_halo_exchange(void *d_vec, int value_bytes, void *stream);
 int spmv_hip_comm_halo_info(long long *send_values, long long *recv_values, int *peers);
 int spmv_hip_csr_power_iterate_halo(spmv_csr_dev *m, int variant, int iters, double *lambda, float *ms_total);

@@ -194,6 +194,8 @@ _PROTOTYPES = {
     "spmv_hip_csr_power_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, c_double_p,
                                              c_float_p]),
     "spmv_hip_csr_needed_ranges": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
+    "spmv_hip_csr_split_interior": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    "spmv_hip_csr_run_part": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmv_hip_halo_plan": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, C.c_int, C.c_int, c_int_p, c_int_p,
                                      c_int_p, c_int_p]),
     "spmv_hip_comm_halo_setup": (C.c_int, [C.c_void_p, c_int_p]),

@@ -456,6 +456,7 @@ __device__ __forceinline__ void local_stage_full(T *stage, const int *__restrict
 
 template <typename T, bool NT, int CAP>
 __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int xcd_chunk,
+                                                           const int *__restrict__ ids,
                                                            const int4 *__restrict__ desc,
                                                            const int2 *__restrict__ ldesc,
                                                            const int *__restrict__ lines,
@@ -470,8 +471,10 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
     extern __shared__ __attribute__((aligned(16))) unsigned char local_smem[];
     T *stage = reinterpret_cast<T *>(local_smem);
 
-    const int b = xcd_chunked(blockIdx.x, xcd_chunk);
-    if (b >= num_blocks) return;
+    const int at = xcd_chunked(blockIdx.x, xcd_chunk);
+    if (at >= num_blocks) return;
+    // ids (optional): a sub-list of the blocks -- the interior or the boundary blocks of a rank (N4 overlap)
+    const int b = ids ? ids[at] : at;
     const int t = threadIdx.x;
     const int4 d = desc[b];
     const int2 ld = ldesc[b];

@@ -468,6 +468,7 @@ struct halo_segment {
 std::vector<halo_segment> g_halo_send, g_halo_recv;
 bool g_halo_ready = false;
 
+
 // merge sorted, possibly touching ranges; then close the smallest gaps until at most max_ranges remain
 void squeeze_ranges(std::vector<std::pair<int, int>> &r, int max_ranges) {
     std::vector<std::pair<int, int>> out;
@@ -572,7 +573,7 @@ constexpr int kHaloSegments = 4096;  // segments a rank sends / receives
 
 // Collective: every rank publishes what its handle needs (all-gather of a small fixed-size record), derives
 // its send / receive segments with spmv_hip_halo_plan, and keeps them for spmv_hip_comm_halo_exchange.
-static int spmv_hip_comm_halo_setup_body(const spmv_csr_dev *m, const int *bounds) {
+static int spmv_hip_comm_halo_setup_body(spmv_csr_dev *m, const int *bounds) {
     if (need_device()) return -1;
     if (!g_comm) return fail("comm_halo_setup: no communicator");
     if (!m || !bounds) return fail("comm_halo_setup: NULL argument");
@@ -610,10 +611,12 @@ static int spmv_hip_comm_halo_setup_body(const spmv_csr_dev *m, const int *bound
         g_halo_ready = true;
     } while (0);
     (void)hipFree(d_all);
+    // which of the handle's blocks can run while the halo is travelling
+    if (!rc) rc = spmv_hip_csr_split_interior(m, nullptr);
     return rc;
 }
 
-extern "C" int spmv_hip_comm_halo_setup(const spmv_csr_dev *m, const int *bounds) {
+extern "C" int spmv_hip_comm_halo_setup(spmv_csr_dev *m, const int *bounds) {
     return guarded("comm_halo_setup", [&] { return spmv_hip_comm_halo_setup_body(m, bounds); });
 }
 
@@ -673,22 +676,49 @@ __global__ void norm_from_sum(const double *__restrict__ sum, double *__restrict
     norm[1] = nrm > 0 ? 1.0 / nrm : 0.0;
 }
 
+// One step: y_own = A x on this rank's rows, partial norm, all-reduce, x_own = y_own / norm, halo of x to the
+// neighbours.  With a communicator and an interior / boundary split of the handle's blocks
+// (spmv_hip_csr_split_interior) the exchange runs on the second stream BESIDE the interior blocks of the next
+// product -- they read this rank's own range of x only -- and the boundary blocks wait for it:
+//     stream 1:  ... scale x_own | E1 | interior blocks ........ | wait E2 | boundary blocks, norm, all-reduce, scale ...
+//     stream 2:                  wait E1 | halo send / recv | E2
+// The same kernels on the same blocks with the same x as the serial order: identical bits.
 template <typename T>
-int power_iterations_halo(spmv_csr_dev *m, int variant, int iters, double *d_part, double *d_sum, double *d_norm) {
+int power_iterations_halo(spmv_csr_dev *m, int variant, int iters, double *d_part, double *d_sum, double *d_norm,
+                          hipEvent_t scaled, hipEvent_t arrived) {
     const long long n = m->M_local;
     const int grid = (int)std::max<long long>(1, std::min<long long>(kNormBlocks, (n + kBlock - 1) / kBlock));
     T *y_own = (T *)m->y + m->row0, *x_own = (T *)m->x + m->row0;
+    const bool overlap = g_comm && m->have_split && g_halo_overlap && (variant == SPMV_CSR_AUTO || variant == SPMV_CSR_STREAM);
+    bool in_flight = false;  // a halo exchange of the current x is under way on the second stream
     for (int i = 0; i < iters; ++i) {
-        if (csr_launch_any(m, variant, m->x, m->y, g_stream)) return -1;
+        if (overlap) {
+            if (csr_launch_part(m, 0, m->x, m->y, g_stream)) return -1;  // interior: own x only
+            if (in_flight) HIP_TRY(hipStreamWaitEvent(g_stream, arrived, 0));
+            in_flight = false;
+            if (csr_launch_part(m, 1, m->x, m->y, g_stream)) return -1;  // boundary blocks + split rows
+        } else {
+            if (csr_launch_any(m, variant, m->x, m->y, g_stream)) return -1;
+        }
         hipLaunchKernelGGL((norm2_partial<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)y_own, n, d_part);
         hipLaunchKernelGGL(fold_partials, dim3(1), dim3(kBlock), 0, g_stream, d_part, grid, d_sum);
         if (g_comm) {
-            const ncclResult_t n = ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, g_comm, g_stream);
-            if (n != ncclSuccess) return fail("power_iterate_halo: ncclAllReduce failed: %s", ncclGetErrorString(n));
+            const ncclResult_t nr = ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, g_comm, g_stream);
+            if (nr != ncclSuccess) return fail("power_iterate_halo: ncclAllReduce failed: %s", ncclGetErrorString(nr));
         }
         hipLaunchKernelGGL(norm_from_sum, dim3(1), dim3(1), 0, g_stream, d_sum, d_norm);
         hipLaunchKernelGGL((scale_into<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)y_own, n, d_norm, x_own);
-        if (g_comm && spmv_hip_comm_halo_exchange(m->x, m->value_bytes, g_stream)) return -1;
+        if (g_comm) {
+            if (overlap && i + 1 < iters) {
+                HIP_TRY(hipEventRecord(scaled, g_stream));
+                HIP_TRY(hipStreamWaitEvent(g_stream2, scaled, 0));
+                if (spmv_hip_comm_halo_exchange(m->x, m->value_bytes, g_stream2)) return -1;
+                HIP_TRY(hipEventRecord(arrived, g_stream2));
+                in_flight = true;
+            } else if (spmv_hip_comm_halo_exchange(m->x, m->value_bytes, g_stream)) {
+                return -1;
+            }
+        }
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -706,7 +736,7 @@ extern "C" int spmv_hip_csr_power_iterate_halo(spmv_csr_dev *m, int variant, int
     if (m->M_total != m->N) return fail("power_iterate_halo: needs a square matrix (%d x %d)", m->M_total, m->N);
     if (g_comm && !g_halo_ready) return fail("power_iterate_halo: call spmv_hip_comm_halo_setup first");
     double *d_part = nullptr, *d_sum = nullptr, *d_norm = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, scaled = nullptr, arrived = nullptr;
     int rc = 0;
     do {
         hipError_t e = hipMalloc((void **)&d_part, kNormBlocks * sizeof(double));
@@ -714,11 +744,17 @@ extern "C" int spmv_hip_csr_power_iterate_halo(spmv_csr_dev *m, int variant, int
         if (e == hipSuccess) e = hipMalloc((void **)&d_norm, 2 * sizeof(double));
         if (e == hipSuccess) e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&scaled, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&arrived, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
         if (e != hipSuccess) { rc = fail("power_iterate_halo: setup failed: %s", hipGetErrorString(e)); break; }
-        rc = m->value_bytes == 8 ? power_iterations_halo<double>(m, variant, iters, d_part, d_sum, d_norm)
-                                 : power_iterations_halo<float>(m, variant, iters, d_part, d_sum, d_norm);
-        if (rc) break;
+        rc = m->value_bytes == 8 ? power_iterations_halo<double>(m, variant, iters, d_part, d_sum, d_norm, scaled, arrived)
+                                 : power_iterations_halo<float>(m, variant, iters, d_part, d_sum, d_norm, scaled, arrived);
+        if (rc) {
+            (void)hipStreamSynchronize(g_stream2);  // nothing of the loop may outlive its events
+            (void)hipStreamSynchronize(g_stream);
+            break;
+        }
         e = hipEventRecord(e1, g_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
         float ms = 0;
@@ -731,6 +767,8 @@ extern "C" int spmv_hip_csr_power_iterate_halo(spmv_csr_dev *m, int variant, int
     } while (0);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (scaled) (void)hipEventDestroy(scaled);
+    if (arrived) (void)hipEventDestroy(arrived);
     (void)hipFree(d_part);
     (void)hipFree(d_sum);
     (void)hipFree(d_norm);

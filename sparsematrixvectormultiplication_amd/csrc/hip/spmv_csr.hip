@@ -745,6 +745,8 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->ldesc);
     (void)hipFree(m->lines);
     (void)hipFree(m->lcol);
+    (void)hipFree(m->interior_ids);
+    (void)hipFree(m->boundary_ids);
     (void)hipFree(m->tile_block_pass);
     (void)hipFree(m->tile_block_row);
     (void)hipFree(m->tile_pass);
@@ -830,7 +832,7 @@ void launch_vector(const spmv_csr_dev *m, const T *x, T *y, hipStream_t s) {
 }
 
 template <typename T>
-int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStream_t s) {
+int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStream_t s, int part = -1) {
     if (m->M_local == 0) return 0;
     T *y = y_full + m->row0;
     if (variant == SPMV_CSR_AUTO) variant = m->auto_variant;
@@ -914,12 +916,15 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                 if (local) {
                     // runs of 16 neighbouring blocks per XCD: each L2 keeps its own window of x lines
                     // (measured flat from 8 to 128 on three matrices); stream_xcd overrides
-                    const int lchunk = g_stream_xcd < 0 ? (m->local_blocks + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
-                    const int lgrid = lchunk > 0 ? (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk)
-                                                 : m->local_blocks;
+                    // part < 0: all blocks; 0 / 1: the interior / boundary sub-list (csr_launch_part)
+                    const int lcount = part < 0 ? m->local_blocks : part == 0 ? m->num_interior : m->num_boundary;
+                    const int *lids = part < 0 ? nullptr : part == 0 ? m->interior_ids : m->boundary_ids;
+                    const int lchunk = g_stream_xcd < 0 ? (lcount + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
+                    const int lgrid = lchunk > 0 ? (lcount + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk) : lcount;
+                    if (lcount > 0) {
                     const size_t lds = std::max((size_t)m->local_cap * sizeof(T), (size_t)m->local_stage_lines * kLineBytes);
 #define SPMV_LOCAL(NT, CAP)                                                                                   \
-    hipLaunchKernelGGL((csr_stream_local<T, NT, CAP>), dim3(lgrid), dim3(kBlock), lds, s, m->local_blocks, lchunk, \
+    hipLaunchKernelGGL((csr_stream_local<T, NT, CAP>), dim3(lgrid), dim3(kBlock), lds, s, lcount, lchunk, lids,   \
                        m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const T *)m->val, x, y)
                     // streamed-once hint only when the matrix cannot live in the 256 MiB Infinity Cache anyway
                     // (cant-like, 53 MB: 10.9 us without it, 11.7 us with; fem-large: 160 vs 151 us)
@@ -927,6 +932,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     if (m->local_cap == 1024) { if (lnt) SPMV_LOCAL(true, 1024); else SPMV_LOCAL(false, 1024); }
                     else if (m->local_cap == 3072) { if (lnt) SPMV_LOCAL(true, 3072); else SPMV_LOCAL(false, 3072); }
                     else { if (lnt) SPMV_LOCAL(true, 2048); else SPMV_LOCAL(false, 2048); }
+                    }
 #undef SPMV_LOCAL
 #ifdef SPMV_EXPERIMENTAL
                 } else if (g_stream_kind == 4 && m->ring_ok) {
@@ -997,7 +1003,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
 #undef SPMV_LAUNCH_PROD
 #undef SPMV_ARGS
             }
-            if (m->num_long) {
+            if (m->num_long && part != 0) {
                 hipLaunchKernelGGL((csr_long_pieces<T, true>), dim3(m->num_partial), dim3(kBlock), 0, s,
                                    m->num_partial, m->pieces, m->col, (const T *)m->val, x,
                                    (T *)m->partial);
@@ -1018,6 +1024,82 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
 int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s) {
     if (m->value_bytes == 8) return csr_launch<double>(m, variant, (const double *)x, (double *)y, s);
     return csr_launch<float>(m, variant, (const float *)x, (float *)y, s);
+}
+
+// N4 overlap: the interior x-window blocks (part 0: rows whose x lines all lie in the handle's own range, so
+// they can run while the halo of x is still travelling) / everything else (part 1).  Together = one
+// csr_launch_any(STREAM): the same kernels on the same blocks, hence the same bits.  A handle without the
+// split (no x-window plan, foreign misaligned x) runs everything as part 1.
+int csr_launch_part(const spmv_csr_dev *m, int part, const void *x, void *y, hipStream_t s) {
+    const bool split_ok = m->have_split && m->local_blocks > 0 && ((uintptr_t)x & (kLineBytes - 1)) == 0 &&
+                          (g_stream_kind == -1 || g_stream_kind == 5);
+    if (!split_ok) return part == 0 ? 0 : csr_launch_any(m, SPMV_CSR_STREAM, x, y, s);
+    if (m->value_bytes == 8) return csr_launch<double>(m, SPMV_CSR_STREAM, (const double *)x, (double *)y, s, part);
+    return csr_launch<float>(m, SPMV_CSR_STREAM, (const float *)x, (float *)y, s, part);
+}
+
+// Which x-window blocks of the handle are interior: every x line they list lies inside the handle's own rows'
+// range of x (square matrix, x owned like y: entries [row0, row0 + M_local)).  Computed from the plan's line
+// lists (ascending inside a block: first and last line decide).  counts (optional, 4 values): interior blocks,
+// boundary blocks, entries in interior blocks, entries in boundary blocks + split rows.
+static int csr_split_interior_body(spmv_csr_dev *m, long long *counts) {
+    if (need_device()) return -1;
+    if (!m) return fail("csr_split_interior: NULL handle");
+    if (m->M_total != m->N) return fail("csr_split_interior: needs a square matrix (%d x %d)", m->M_total, m->N);
+    (void)hipFree(m->interior_ids);
+    (void)hipFree(m->boundary_ids);
+    m->interior_ids = m->boundary_ids = nullptr;
+    m->num_interior = m->num_boundary = 0;
+    m->have_split = false;
+    long long e_in = 0, e_out = m->nz;
+    if (m->local_blocks > 0) {
+        const int B = m->local_blocks;
+        std::vector<int2> ld((size_t)B);
+        std::vector<int4> d4((size_t)B);
+        std::vector<int> lines((size_t)m->local_lines);
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipMemcpy(ld.data(), m->ldesc, ld.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d4.data(), m->ldesc4, d4.size() * sizeof(int4), hipMemcpyDeviceToHost));
+        if (!lines.empty()) HIP_TRY(hipMemcpy(lines.data(), m->lines, lines.size() * sizeof(int), hipMemcpyDeviceToHost));
+        const int per_line = kLineBytes / m->value_bytes;
+        const long long own_lo = m->row0, own_hi = (long long)m->row0 + m->M_local;  // [lo, hi) of x
+        std::vector<int> in_ids, out_ids;
+        for (int b = 0; b < B; ++b) {
+            const long long first = (long long)lines[(size_t)ld[b].x] * per_line;
+            const long long last = ((long long)lines[(size_t)ld[b].x + ld[b].y - 1] + 1) * per_line;  // exclusive
+            // (a block of empty rows lists line 0 only to have something to stage: it reads nothing)
+            const bool empty = d4[b].w == d4[b].y;
+            if (empty || (first >= own_lo && std::min<long long>(last, m->N) <= own_hi)) {
+                in_ids.push_back(b);
+                e_in += d4[b].w - d4[b].y;
+            } else {
+                out_ids.push_back(b);
+            }
+        }
+        e_out = m->nz - e_in;
+        if (upload_array(&m->interior_ids, in_ids.data(), in_ids.size(), 1)) return -1;
+        if (upload_array(&m->boundary_ids, out_ids.data(), out_ids.size(), 1)) return -1;
+        m->num_interior = (int)in_ids.size();
+        m->num_boundary = (int)out_ids.size();
+        m->have_split = true;
+    }
+    if (counts) {
+        counts[0] = m->num_interior;
+        counts[1] = m->num_boundary;
+        counts[2] = e_in;
+        counts[3] = e_out;
+    }
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_split_interior(spmv_csr_dev *m, long long *counts) {
+    return guarded("csr_split_interior", [&] { return csr_split_interior_body(m, counts); });
+}
+
+extern "C" int spmv_hip_csr_run_part(spmv_csr_dev *m, int part, const void *d_x, void *d_y, void *stream) {
+    if (need_device()) return -1;
+    if (!m || (part != 0 && part != 1)) return fail("csr_run_part: bad arguments");
+    return csr_launch_part(m, part, d_x ? d_x : m->x, d_y ? d_y : m->y, stream ? (hipStream_t)stream : g_stream);
 }
 
 

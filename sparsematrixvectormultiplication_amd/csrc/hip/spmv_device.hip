@@ -24,6 +24,7 @@ __global__ __launch_bounds__(kBlock) void flush_kernel(uint4 *__restrict__ buf, 
 static thread_local char g_error[512] = "";
 int g_device = -1;
 hipStream_t g_stream = nullptr;
+hipStream_t g_stream2 = nullptr;
 static void *g_flush_buf = nullptr;
 static size_t g_flush_bytes = 0;
 ncclComm_t g_comm = nullptr;
@@ -45,6 +46,7 @@ int g_tile_lmax = 16384;
 int g_tile_density = 16;
 int g_tile_chunk = 0;
 int g_tile_probe = 0;
+int g_halo_overlap = 1;
 int g_tile_balance = 1;
 int g_pipe_wgs_per_cu = 5;
 int g_num_cus = 256;
@@ -83,8 +85,11 @@ extern "C" int spmv_hip_init(int device) {
     if (g_stream && g_device != device) {
         (void)hipStreamDestroy(g_stream);
         g_stream = nullptr;
+        if (g_stream2) (void)hipStreamDestroy(g_stream2);
+        g_stream2 = nullptr;
     }
     if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_stream2) HIP_TRY(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
     // SPMV_TUNING="key=value,key=value": same keys as spmv_hip_set_tuning (profiling aid)
     if (const char *env = getenv("SPMV_TUNING")) {
         std::string all(env);
@@ -116,6 +121,10 @@ extern "C" int spmv_hip_shutdown(void) {
         (void)hipFree(g_flush_buf);
         g_flush_buf = nullptr;
         g_flush_bytes = 0;
+    }
+    if (g_stream2) {
+        (void)hipStreamDestroy(g_stream2);
+        g_stream2 = nullptr;
     }
     if (g_stream) {
         (void)hipStreamDestroy(g_stream);
@@ -164,6 +173,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "tile_chunk")) {
         if (value != 0 && value != 2048 && value != 4096) return fail("set_tuning: tile_chunk must be 0 (auto), 2048 or 4096");
         g_tile_chunk = value;
+    } else if (!strcmp(key, "halo_overlap")) {
+        g_halo_overlap = value != 0;
     } else if (!strcmp(key, "tile_balance")) {
         g_tile_balance = value != 0;
     } else if (!strcmp(key, "tile_probe")) {

@@ -27,6 +27,7 @@ using namespace spmv;
 // ------------------------------------------------------------------ state (spmv_device.hip)
 extern int g_device;
 extern hipStream_t g_stream;
+extern hipStream_t g_stream2;  // second stream: the halo exchange that runs beside the interior blocks
 extern ncclComm_t g_comm;
 extern int g_comm_rank, g_comm_size;
 
@@ -36,6 +37,7 @@ extern int g_stream_block;    // threads per csr_stream workgroup
 extern int g_stream_nt;       // non-temporal loads for col/val in the gather stream kernels
 extern int g_local_nt;        // same for the x-window kernels: -1 = auto (off while the matrix fits the Infinity Cache)
 extern int g_stream_xcd;      // blocks per XCD run (xcd_chunked); 0 = default, -1 = one contiguous eighth per XCD
+extern int g_halo_overlap;    // power iteration with halo: exchange beside the interior blocks (1) or strictly in order (0)
 extern int g_gather_mode;     // all-gatherv: 0 = one ncclBroadcast per owner in a group, 1 = padded ncclAllGather + scatter
 extern int g_local_cap;       // stage of the x-window plan: 0 = auto, 1024 or 2048
 extern int g_stream_local;    // build the x-window plan at upload when it pays
@@ -132,6 +134,10 @@ struct spmv_csr_dev {
     int local_stage_lines = 0;        // LDS stage: most lines any block lists, in steps of 32
     int local_cap = 2048;
     long long local_lines = 0;
+    // N4 overlap: x-window blocks whose listed x lines all lie in this handle's own range of x (interior) / the rest
+    int *interior_ids = nullptr, *boundary_ids = nullptr;
+    int num_interior = 0, num_boundary = 0;
+    bool have_split = false;
     // csr_tile (2-D tiles: row-block accumulators in LDS x column passes), for matrices without an x-window plan
     int tile_blocks = 0;              // 0: no tiles
     int tile_rows = 0;                // rows per block
@@ -204,6 +210,8 @@ int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_v
 
 // launchers the timing / exchange code calls across translation units
 int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s);
+// part 0: the interior x-window blocks only; part 1: everything else (boundary blocks, split rows)
+int csr_launch_part(const spmv_csr_dev *m, int part, const void *x, void *y, hipStream_t s);
 int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_full, hipStream_t s);
 
 // ------------------------------------------------------------------ timing loops

@@ -196,6 +196,18 @@ class CsrDevice(_Handle):
                "csr_power_iterate")
         return float(lam.value), float(ms.value)
 
+    def split_interior(self) -> dict:
+        """Split the x-window blocks into interior (own range of x only) and boundary ones
+        (spmv_hip_csr_split_interior); returns the block and entry counts."""
+        counts = (C.c_longlong * 4)()
+        _check(nat.lib().spmv_hip_csr_split_interior(self.h, counts), "spmv_hip_csr_split_interior")
+        return dict(zip(("interior_blocks", "boundary_blocks", "interior_entries", "boundary_entries"),
+                        (int(v) for v in counts)))
+
+    def run_part(self, part: int):
+        """part 0: interior blocks only; part 1: the rest (asynchronous on the library stream)."""
+        _check(nat.lib().spmv_hip_csr_run_part(self.h, int(part), None, None, None), "spmv_hip_csr_run_part")
+
     def power_iterate_halo(self, iters, variant=CSR_AUTO):
         """power_iterate with the halo exchange (NativeComm.halo_setup first when a communicator exists)."""
         lam, ms = C.c_double(0), C.c_float(0)

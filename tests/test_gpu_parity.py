@@ -966,6 +966,67 @@ def test_power_iteration_with_halo_exchange_emulated_ranks(gpu, oracle):
             d.close()
 
 
+def test_interior_and_boundary_blocks_emulated_ranks(gpu, oracle):
+    """SURVEY 8(f) N4, overlap: a rank's x-window blocks split into interior blocks (own range of x only) and
+    boundary blocks.  Three emulated ranks: the interior part runs while the halo of x is still NaN, the boundary
+    part after it has 'arrived'; the two parts together must give the bits of the one-launch product, and no NaN
+    may survive (an interior block that read a halo entry would leave one).  Also the shares."""
+    from sparsematrixvectormultiplication_amd.distributed import halo_plan, needed_ranges
+    from _util import banded_csr
+    rng = np.random.default_rng(64)
+    n = 30000
+    row_ptr, col, val = banded_csr(rng, n, n, 22, 150)
+    lens = np.diff(row_ptr)
+    x0 = rng.uniform(0.5, 1.0, n)
+    bounds = sp.partition_rows(row_ptr, 3)
+    devs = [sp.CsrDevice(n, n, row_ptr, col, val, row0=int(bounds[r]), row1=int(bounds[r + 1])) for r in range(3)]
+    try:
+        needs = [needed_ranges(d) for d in devs]
+        plans = [halo_plan(r, bounds, needs) for r in range(3)]
+        for r, d in enumerate(devs):
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            counts = d.split_interior()
+            info = d.info()
+            assert counts["interior_blocks"] + counts["boundary_blocks"] == info["local_blocks"] > 0
+            assert counts["interior_entries"] + counts["boundary_entries"] == info["nz"]
+            assert counts["interior_blocks"] > 0.7 * info["local_blocks"]     # a band of +-150 in ~10 000 rows
+            assert counts["boundary_blocks"] > 0                              # ... but the ends do reach out
+            x_full = np.full(n, np.nan)
+            x_full[lo:hi] = x0[lo:hi]
+            for q, a, b in plans[r][1]:
+                x_full[a:b] = x0[a:b]
+            d.set_x(x_full)
+            d.run(sp.CSR_STREAM)
+            y_one = d.get_y()[lo:hi].copy()
+            assert not np.any(np.isnan(y_one))
+            x_own = np.full(n, np.nan)
+            x_own[lo:hi] = x0[lo:hi]                                          # the halo has not arrived
+            d.set_x(x_own)
+            sp.lib().spmv_hip_memset(d.y_ptr, 0xFF, n * 8)
+            d.run_part(0)
+            y_mid = d.get_y()[lo:hi].copy()
+            done = ~np.isnan(y_mid)                                           # rows of interior blocks
+            assert done.sum() > 0.7 * (hi - lo) and np.array_equal(y_mid[done], y_one[done])
+            d.set_x(x_full)                                                   # ... now it has
+            d.run_part(1)
+            y_two = d.get_y()[lo:hi]
+            assert y_two.tobytes() == y_one.tobytes()
+        # a handle without an x-window plan has no interior: everything runs as part 1
+        rp2, c2, v2 = random_csr(rng, 2000, 2000, 30, 60, 0.0)
+        with sp.CsrDevice(2000, 2000, rp2, c2, v2) as scattered:
+            if not scattered.info()["local_blocks"]:
+                assert scattered.split_interior()["interior_blocks"] == 0
+                xs = rng.uniform(-1, 1, 2000)
+                y_ref = scattered.spmv(xs, sp.CSR_STREAM)
+                sp.lib().spmv_hip_memset(scattered.y_ptr, 0xFF, 2000 * 8)
+                scattered.run_part(0)
+                scattered.run_part(1)
+                assert scattered.get_y().tobytes() == y_ref.tobytes()
+    finally:
+        for d in devs:
+            d.close()
+
+
 def test_power_iteration_halo_single_rank_communicator(gpu):
     """The RCCL side at world size 1: setup (all-gather of the needs record), an exchange with no peers, the
     all-reduce of the norm; the halo loop then gives the plain loop's result bit for bit."""
@@ -985,7 +1046,15 @@ def test_power_iteration_halo_single_rank_communicator(gpu):
             assert info == {"send_values": 0, "recv_values": 0, "peers": 0}
             comm.halo_exchange(dev.x_ptr, 8)
             dev.set_x(x0)
-            lam_halo, ms = dev.power_iterate_halo(4)
+            lam_halo, ms = dev.power_iterate_halo(4)       # exchange on the second stream beside the interior blocks
             assert ms > 0 and lam_halo == lam_plain and dev.get_x().tobytes() == x_plain.tobytes()
+            from sparsematrixvectormultiplication_amd.device import set_tuning
+            set_tuning("halo_overlap", 0)                  # strictly in order: the same bits
+            try:
+                dev.set_x(x0)
+                lam_serial, _ = dev.power_iterate_halo(4)
+                assert lam_serial == lam_plain and dev.get_x().tobytes() == x_plain.tobytes()
+            finally:
+                set_tuning("halo_overlap", 1)
         finally:
             comm.close()
