@@ -362,6 +362,23 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
                          "kernel": ("csr_stream", "csr_stream_local", "csr_stream_short")[info["stream_kernel"]],
                          "format_bytes": info["stream_bytes"] or info["algo_bytes"],
                          "us": round(float(ms.mean()) * 1e3, 2)}}
+    if which == "powerlaw_f32":
+        # BASELINE configs[4] at full size on ONE GPU (the 8-GPU run is the driver's): 2^24 rows, 2.6e8 nnz, fp32
+        n, row_ptr, col, val = synth.powerlaw()
+        nnz = int(row_ptr[-1])
+        with sp.CsrDevice(n, n, row_ptr, col, val) as dev:
+            dev.set_x(np.ones(n, dtype=np.float32))
+            info = dev.info()
+            ms = dev.time(sp.CSR_AUTO, warmup, max(5, steps // 4), zero_y=True)
+        from sparsematrixvectormultiplication_amd.device import CSR_STREAM_KERNELS
+        return {"workload": "power-law 2^24 x 2^24 fp32 CSR (config 5 on one GPU; no reference counterpart for fp32)",
+                "rows": n, "nnz": nnz, "algo_bytes": info["algo_bytes"],
+                "auto": {"kernel": CSR_STREAM_KERNELS[info["stream_kernel"]], "ms": round(float(ms.mean()), 4),
+                         "gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
+                         "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
+                         "pct_of_8TBs": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9 / 80.0, 2),
+                         "rows_in_split_row_kernels": info["tile_split_rows"],
+                         "entries_in_tiles": info["tile_entries"], "format_bytes": info["stream_bytes"]}}
     M, row_ptr, col, val = synth.fem_like()
     nnz = int(row_ptr[-1])
     x = np.ones(M)
@@ -710,7 +727,8 @@ def main():
         try:
             result["also"] = [side_measurement(sp, synth, "cant_csr", K, W),
                               side_measurement(sp, synth, "cant_hll", K, W, cpu_sweep=not (args.no_cpu_baseline or args.no_cpu_sweep)),
-                              side_measurement(sp, synth, "fem_large_csr", K, W)]
+                              side_measurement(sp, synth, "fem_large_csr", K, W),
+                              side_measurement(sp, synth, "powerlaw_f32", K, W)]
         except Exception as exc:  # side numbers must never lose the headline line
             result["also"] = [{"error": str(exc)}]
     if comm is not None:

@@ -232,8 +232,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
                                                         const int4 *__restrict__ desc,
                                                         const int4 *__restrict__ ldesc,
                                                         const int *__restrict__ lines,
-                                                        const long long *__restrict__ hack_off,
-                                                        const int *__restrict__ maxnz,
+                                                        const unsigned *__restrict__ row_seg,
                                                         const unsigned short *__restrict__ lja,
                                                         const T *__restrict__ AS,
                                                         const T *__restrict__ x, T *__restrict__ y) {
@@ -251,11 +250,12 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
     const long long first_slot = ((long long)d.w << 32) | (unsigned)d.z;
     const long long base = first_slot & ~1LL;
 
+    // a row's slots inside its window, precomputed at upload (hll_row_segments): one 4-byte load per lane
+    // where the hack tables cost two loads and 64-bit arithmetic (nlpkkt-like: 208 -> see profiles/r2_hll_*)
     auto row_range = [&](int q, int &lo, int &m) {
-        const int r = row_first + q;
-        const int h = r / kHack;
-        m = maxnz[h];
-        lo = (int)(hack_off[h] + (long long)(r % kHack) * m - base);
+        const unsigned seg = row_seg[row_first + q];
+        lo = (int)(seg & 0xffffu);
+        m = (int)(seg >> 16);
     };
     const int lanes = lanes_for_rows<kBlock>(nrows);
     const int rows_per_pass = kBlock / lanes;
@@ -313,6 +313,24 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
         T acc = lds_strided_sum(stage, lo, lo + m_row, my_lane, lanes);
         acc = group_sum_rt(acc, lanes);
         if (my_lane == 0 && q < nrows) y[row_first + q] = acc;
+    }
+}
+
+// row_seg[r] = (first slot of row r relative to its window's even base) | (slots of the row << 16), for the
+// rows of the x-window plan's windows: what hll_lds_local's row-sum phase needs, in one word.
+static __global__ __launch_bounds__(kBlock) void hll_row_segments(int num_blocks, const int4 *__restrict__ desc,
+                                                           const long long *__restrict__ hack_off,
+                                                           const int *__restrict__ maxnz,
+                                                           unsigned *__restrict__ row_seg) {
+    const int b = blockIdx.x;
+    if (b >= num_blocks) return;
+    const int4 d = desc[b];
+    const long long base = (((long long)d.w << 32) | (unsigned)d.z) & ~1LL;
+    for (int q = threadIdx.x; q < d.y; q += kBlock) {
+        const int r = d.x + q, h = r / kHack;
+        const int m = maxnz[h];
+        const long long lo = hack_off[h] + (long long)(r % kHack) * m - base;
+        row_seg[r] = (unsigned)lo | ((unsigned)m << 16);
     }
 }
 

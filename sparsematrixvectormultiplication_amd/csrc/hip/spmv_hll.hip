@@ -130,6 +130,18 @@ long long hll_offsets(int total_rows, const std::vector<int> &mz, std::vector<lo
 }
 
 // workgroup windows, small arrays and vectors of a handle whose JA / AS are already on the device
+// row_seg for the rows of the x-window plan's windows (hack tables and window descriptors are on the device)
+int hll_fill_row_segments(spmv_hll_dev *m) {
+    HIP_TRY(hipMalloc((void **)&m->row_seg, std::max<size_t>((size_t)m->M, 1) * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(m->row_seg, 0, std::max<size_t>((size_t)m->M, 1) * sizeof(unsigned), g_stream));
+    hipLaunchKernelGGL(hll_row_segments, dim3(m->local_blocks), dim3(kBlock), 0, g_stream, m->local_blocks, m->ldesc4,
+                       m->hack_off, m->maxnz, m->row_seg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    m->device_bytes += (size_t)m->M * sizeof(unsigned);
+    return 0;
+}
+
 int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<long long> &off,
                       const std::vector<int> &mz, long long true_slots, bool upload_maxnz, const int *ja_host,
                       int matrix_rows = -1, int row0 = 0) {
@@ -179,6 +191,7 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
             }
         }
     }
+    if (!rc && m->local_blocks > 0) rc = hll_fill_row_segments(m);
     const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
     m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
     return rc;
@@ -528,6 +541,7 @@ extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
     (void)hipFree(m->ldesc);
     (void)hipFree(m->lines);
     (void)hipFree(m->lja);
+    (void)hipFree(m->row_seg);
     (void)hipFree(m->x);
     (void)hipFree(m->y);
     delete m;
@@ -616,11 +630,11 @@ int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_fu
                 const bool lnt = g_local_nt < 0 ? m->slots * 10 > (128LL << 20) : g_local_nt != 0;
                 if (lnt)
                     hipLaunchKernelGGL((hll_lds_local<double, true, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
-                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_seg,
                                        m->lja, m->AS, x, y);
                 else
                     hipLaunchKernelGGL((hll_lds_local<double, false, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
-                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->hack_off, m->maxnz,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_seg,
                                        m->lja, m->AS, x, y);
                 break;
             }

@@ -179,6 +179,7 @@ struct spmv_hll_dev {
     int4 *ldesc = nullptr;  // {first line, lines, slots of the window from its even base, 0}
     int *lines = nullptr;
     unsigned short *lja = nullptr;
+    unsigned *row_seg = nullptr;   // [M] a row's (first slot in its window | slots << 16)
     int local_blocks = 0, local_stage_lines = 0;
     long long local_lines = 0;
     double *x = nullptr;

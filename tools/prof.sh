@@ -3,7 +3,7 @@
 #   bash tools/prof.sh <tag> [extra bench args]
 # Writes gpurun_out/prof_<tag>/{trace,pmc_*}/...; copy the summaries you want judged into profiles/.
 set -e
-TAG=${1:-r1}; shift || true
+TAG=${1:-r2}; shift || true
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
