@@ -60,13 +60,14 @@ import numpy as np  # noqa: E402
 
 KERNEL_SOURCES = {  # the file a kernel's code lives in: a traffic measurement belongs to one revision of it
     "csr": os.path.join(ROOT, "sparsematrixvectormultiplication_amd", "csrc", "hip", "csr_kernels.hpp"),
+    "tile": os.path.join(ROOT, "sparsematrixvectormultiplication_amd", "csrc", "hip", "tile_kernels.hpp"),
     "hll": os.path.join(ROOT, "sparsematrixvectormultiplication_amd", "csrc", "hip", "hll_kernels.hpp"),
 }
 
 
 def kernel_source_sha(kernel):
     import hashlib
-    path = KERNEL_SOURCES["hll" if kernel.startswith("hll") else "csr"]
+    path = KERNEL_SOURCES["hll" if kernel.startswith("hll") else "tile" if kernel == "csr_tile" else "csr"]
     try:
         return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
     except OSError:

@@ -93,6 +93,10 @@ typedef struct {
     int tile_split_rows;   /* CSR: rows beyond the tile limit (split-row kernels, stripe-ordered pieces) */
     long long tile_entries;        /* CSR: entries held by the tiles */
     long long tile_staged_entries; /* CSR: ... of which in passes whose x slice is staged in LDS */
+    int tile_long_rows;            /* CSR: rows beyond the tile limit that got the long-row tile plan (compacted rows,
+                                      a block's passes dealt out to many workgroups, slabs added in order) */
+    int tile_long_items;           /* CSR: workgroups of that plan */
+    long long tile_long_entries;   /* CSR: entries it holds */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -118,9 +122,10 @@ int spmv_hip_flush_cache(size_t bytes);
  *     "local_cap"     0 (auto = 2048) | 1024 | 2048 | 3072   stage of the x-window kernels (3072: +0.5..3 % on the
  *                     nlpkkt-like matrix depending on the box, -8 % on the cant-like one)
  *     "stream_tile"   -1 (auto) | 0 | 1   build the 2-D tile plan (csr_tile) when the matrix gets no x-window plan;
- *                     "tile_rows" 0 (auto = 2048) | 256..16384 rows per block, "tile_lmax" (16384) longest row kept in
+ *                     "tile_rows" 0 (auto = 2048) | 256..16384 rows per block, "tile_lmax" (1024) longest row kept in
  *                     the tiles, "tile_density" (16) columns per entry up to which a pass is staged in LDS, "tile_chunk" 0 (auto)
- *                     | 2048 | 4096 entries per pass, "tile_balance" 1 | 0 row blocks of equal entry / row counts
+ *                     | 2048 | 4096 entries per pass, "tile_balance" 1 | 0 row blocks of equal entry / row counts, "tile_long" 1 | 0 a tile plan of
+ *                     their own for the rows beyond tile_lmax (else: split-row kernels)
  *   read at launch
  *     "stream_kind"   -1 (auto: x-window kernel when the handle has a plan, csr_tile when it has tiles, else
  *                     csr_stream) | 5 x-window | 6 csr_tile |

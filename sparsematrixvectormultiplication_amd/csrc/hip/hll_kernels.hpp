@@ -316,24 +316,6 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
     }
 }
 
-// row_seg[r] = (first slot of row r relative to its window's even base) | (slots of the row << 16), for the
-// rows of the x-window plan's windows: what hll_lds_local's row-sum phase needs, in one word.
-static __global__ __launch_bounds__(kBlock) void hll_row_segments(int num_blocks, const int4 *__restrict__ desc,
-                                                           const long long *__restrict__ hack_off,
-                                                           const int *__restrict__ maxnz,
-                                                           unsigned *__restrict__ row_seg) {
-    const int b = blockIdx.x;
-    if (b >= num_blocks) return;
-    const int4 d = desc[b];
-    const long long base = (((long long)d.w << 32) | (unsigned)d.z) & ~1LL;
-    for (int q = threadIdx.x; q < d.y; q += kBlock) {
-        const int r = d.x + q, h = r / kHack;
-        const int m = maxnz[h];
-        const long long lo = hack_off[h] + (long long)(r % kHack) * m - base;
-        row_seg[r] = (unsigned)lo | ((unsigned)m << 16);
-    }
-}
-
 // ------------------------------------------------------ CSR -> HLL on the device
 // the reference builds HLL on the host with one qsort and two mallocs
 // per row / hack (src/hll_matrix.c:37-257) and uploads hack by hack.  With the CSR matrix

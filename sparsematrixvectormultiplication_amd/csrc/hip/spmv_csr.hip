@@ -75,6 +75,45 @@ void build_striped_pieces(int M, const int *rp, const int *col, const std::vecto
     for (size_t k = 0; k < tmp.size(); ++k) pieces[k] = tmp[k].d;
 }
 
+// Long-row tile plan.  In: `split` marks the rows the ordinary tiles left out.  Those of them shorter than 2^21
+// entries are compacted (rows[v] = the v-th such row) and given a tile plan of their own with pos_bits = 21;
+// `split` keeps only what this plan does not take.  A block's passes are cut into work items of about equal pass
+// counts, a few thousand in all.  false: nothing to do (fewer than 2^20 entries in such rows).
+template <typename T>
+bool build_long_tiles(int M, int N, const int *rp, const int *row_len, const int *col, const T *val, int chunk,
+                      std::vector<unsigned char> &split, TilePlan<T> &plan, std::vector<int> &rows,
+                      std::vector<int4> &work, std::vector<int> &item_first) {
+    constexpr int kPosBits = 21, kRowsPerBlock = 2048;  // rows of up to 2^21 - 1 entries, 2048 of them per block
+    rows.clear();
+    long long entries = 0;
+    for (int r = 0; r < M; ++r)
+        if (split[(size_t)r] && row_len[r] < (1 << kPosBits)) {
+            rows.push_back(r);
+            entries += row_len[r];
+        }
+    if (rows.empty() || (entries < (1LL << 20) && g_tile_long < 2)) return false;  // (2: whatever the size, tests)
+    std::vector<int> vbegin(rows.size()), vlen(rows.size());
+    for (size_t v = 0; v < rows.size(); ++v) {
+        vbegin[v] = rp[rows[v]];
+        vlen[v] = row_len[rows[v]];
+    }
+    if (!tile_build<T>((int)rows.size(), N, vbegin.data(), vlen.data(), col, val, kRowsPerBlock, (1 << kPosBits) - 1,
+                       g_tile_density, chunk, true, kPosBits, plan))
+        return false;
+    for (int r : rows) split[(size_t)r] = 0;
+    // work items: ~4096 of them over all blocks, at least 4 passes each
+    const long long passes = (long long)plan.pass_desc.size();
+    const int per_item = (int)std::max<long long>(4, (passes + 4095) / 4096);
+    work.clear();
+    item_first.assign(1, 0);
+    for (int b = 0; b < plan.num_blocks; ++b) {
+        for (int p = plan.block_pass[(size_t)b]; p < plan.block_pass[(size_t)b + 1]; p += per_item)
+            work.push_back(int4{b, p, std::min(p + per_item, plan.block_pass[(size_t)b + 1]), (int)work.size()});
+        item_first.push_back((int)work.size());
+    }
+    return true;
+}
+
 bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, int cap, int rows_cap,
                      int line_shift, int lines_max, const std::vector<int4> &baseline, LocalPlan &plan) {
     const int total_lines = (int)(((long long)N + (1 << line_shift) - 1) >> line_shift);
@@ -327,9 +366,10 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     // workgroups sweep x together (L2-resident band), dense passes staged in LDS.  Needs enough row
     // blocks to fill the chip; rows longer than tile_lmax stay with the split-row kernels, their
     // pieces cut at column stripes.
-    TilePlan<T> tiles;
-    bool have_tiles = false, scattered = false;
-    std::vector<int4> tile_pieces, tile_long;
+    TilePlan<T> tiles, ltiles;
+    bool have_tiles = false, scattered = false, have_long_tiles = false;
+    std::vector<int4> tile_pieces, tile_long, lt_work;
+    std::vector<int> lt_rows, lt_item_first;
     if (!have_local && nz > 0 && g_stream_tile != 0 && g_stream_cap == 0) {
         // Rows per block (auto): two regimes, told apart on a sample of the rows.
         //  * banded (most entries in passes that can be staged): 32 KiB of accumulators (4096 fp64 / 8192 fp32
@@ -367,8 +407,10 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
                 std::vector<int> srp((size_t)sample + 1);
                 for (int r = 0; r <= sample; ++r) srp[(size_t)r] = rp[(size_t)s0 + r] - rp[(size_t)s0];
                 TilePlan<T> probe;
-                const bool ok = tile_build<T>(sample, N, srp.data(), hcol + rp[(size_t)s0], hval + rp[(size_t)s0], banded_rows,
-                                              g_tile_lmax, density, chunk, g_tile_balance != 0, probe);
+                std::vector<int> slen((size_t)sample);
+                for (int r = 0; r < sample; ++r) slen[(size_t)r] = srp[(size_t)r + 1] - srp[(size_t)r];
+                const bool ok = tile_build<T>(sample, N, srp.data(), slen.data(), hcol + rp[(size_t)s0], hval + rp[(size_t)s0],
+                                              banded_rows, g_tile_lmax, density, chunk, g_tile_balance != 0, 17, probe);
                 if (ok && probe.staged_entries * 2 >= probe.entries) {
                     rb = banded_rows;
                 } else {
@@ -377,14 +419,24 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
                     scattered = true;
                 }
             }
-            have_tiles = tile_build<T>(Ml, N, rp.data(), hcol, hval, rb, g_tile_lmax, density, chunk, g_tile_balance != 0,
-                                       tiles);
-            // (auto) a matrix made mostly of rows beyond the tile limit gains nothing
-            if (have_tiles && g_stream_tile < 0 && tiles.entries * 2 < nz) have_tiles = false;
+            std::vector<int> row_len((size_t)Ml);
+            for (int r = 0; r < Ml; ++r) row_len[(size_t)r] = rp[(size_t)r + 1] - rp[(size_t)r];
+            have_tiles = tile_build<T>(Ml, N, rp.data(), row_len.data(), hcol, hval, rb, g_tile_lmax, density, chunk,
+                                       g_tile_balance != 0, 17, tiles);
+            // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
+            if (have_tiles && g_stream_tile < 0 && !g_tile_long && tiles.entries * 2 < nz) have_tiles = false;
             if (have_tiles) {
+                // The rows beyond the tile limit, compacted: their own row blocks (<= 2048 of them each), same
+                // passes -- so many entries per column range that every pass is staged: the long rows' x lookups
+                // happen in LDS at the HBM streaming rate instead of going through the gather path -- and a
+                // block's passes dealt out to many workgroups.
+                std::vector<unsigned char> leftover = tiles.split;
+                if (g_tile_long) have_long_tiles = build_long_tiles<T>(Ml, N, rp.data(), row_len.data(), hcol, hval, chunk,
+                                                                        leftover, ltiles, lt_rows, lt_work, lt_item_first);
+                // whatever is left (rows of 2^21 entries and more) stays with the split-row kernels, pieces cut at
                 // stripes of 1 MiB of x: a quarter of an XCD's L2
                 const int stripe_cols = (1 << 20) / (int)sizeof(T);
-                build_striped_pieces(Ml, rp.data(), hcol, tiles.split, stripe_cols, tile_pieces, tile_long);
+                build_striped_pieces(Ml, rp.data(), hcol, leftover, stripe_cols, tile_pieces, tile_long);
             }
         }
     }
@@ -447,6 +499,41 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
             m->tile_padded = (long long)tiles.tcol.size() - kTileChunkMax;
             m->tile_num_long = (int)tile_long.size();
             m->tile_num_pieces = (int)tile_pieces.size();
+        }
+    }
+    if (!rc && have_long_tiles) {
+        auto &L = m->lt;
+        std::vector<int> block_of_row(lt_rows.size());
+        for (int b = 0; b < ltiles.num_blocks; ++b)
+            for (int v = ltiles.block_row[(size_t)b]; v < ltiles.block_row[(size_t)b + 1]; ++v) block_of_row[(size_t)v] = b;
+        rc |= upload_array(&L.block_row, ltiles.block_row.data(), ltiles.block_row.size(), 1);
+        if (!rc) rc |= upload_array(&L.block_pass, ltiles.block_pass.data(), ltiles.block_pass.size(), 1);
+        if (!rc) rc |= upload_array(&L.block_of_row, block_of_row.data(), block_of_row.size(), 1);
+        if (!rc) rc |= upload_array(&L.item_first, lt_item_first.data(), lt_item_first.size(), 1);
+        if (!rc) rc |= upload_array(&L.row_map, lt_rows.data(), lt_rows.size(), 1);
+        if (!rc) rc |= upload_array(&L.pass, ltiles.pass_desc.data(), ltiles.pass_desc.size(), 1);
+        if (!rc) rc |= upload_array(&L.work, lt_work.data(), lt_work.size(), 1);
+        if (!rc) rc |= upload_array(&L.tcol, ltiles.tcol.data(), ltiles.tcol.size(), 0);
+        if (!rc) rc |= upload_array(&L.tkey, ltiles.tkey.data(), ltiles.tkey.size(), 0);
+        if (!rc) rc |= upload_array((T **)&L.tval, ltiles.tval.data(), ltiles.tval.size(), 0);
+        if (!rc) {
+            const size_t slab_bytes = std::max<size_t>(1, lt_work.size()) * (size_t)ltiles.rows_per_block * sizeof(T);
+            hipError_t e = hipMalloc(&L.slab, slab_bytes);
+            if (e != hipSuccess) rc = fail("hipMalloc(slabs) failed: %s", hipGetErrorString(e));
+            m->device_bytes += slab_bytes;
+        }
+        if (!rc) {
+            L.blocks = ltiles.num_blocks;
+            L.rows = (int)lt_rows.size();
+            L.rows_per_block = ltiles.rows_per_block;
+            L.passes = (int)ltiles.pass_desc.size();
+            L.items = (int)lt_work.size();
+            L.max_win = ltiles.max_win;
+            L.entries = ltiles.entries;
+            L.padded = (long long)ltiles.tcol.size() - kTileChunkMax;
+            L.staged = ltiles.staged_entries;
+            m->device_bytes += ltiles.tcol.size() * (6 + sizeof(T)) + ltiles.pass_desc.size() * 16 + lt_work.size() * 16 +
+                               lt_rows.size() * 8;
         }
     }
     const int partial_slots = std::max(num_partial, (int)tile_pieces.size());
@@ -601,7 +688,9 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
     std::vector<T> val((size_t)nz);
     for (long long e = 0; e < nz; ++e) val[(size_t)e] = (T)(1 + e % 7);
     TilePlan<T> plan;
-    if (!tile_build<T>(M, N, rp, col, val.data(), rows_per_block, lmax, density, chunk, balance != 0, plan))
+    std::vector<int> row_len((size_t)M);
+    for (int r = 0; r < M; ++r) row_len[(size_t)r] = rp[r + 1] - rp[r];
+    if (!tile_build<T>(M, N, rp, row_len.data(), col, val.data(), rows_per_block, lmax, density, chunk, balance != 0, 17, plan))
         return fail("tile_plan_check: the plan does not fit 32-bit entry offsets");
     const int win_cols = plan.win_cols;
     auto h = [](long long c, double v) { return (unsigned long long)(c + 1) * 0x9E3779B97F4A7C15ull + (unsigned long long)v; };
@@ -745,6 +834,17 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->ldesc);
     (void)hipFree(m->lines);
     (void)hipFree(m->lcol);
+    (void)hipFree(m->lt.block_row);
+    (void)hipFree(m->lt.block_pass);
+    (void)hipFree(m->lt.block_of_row);
+    (void)hipFree(m->lt.item_first);
+    (void)hipFree(m->lt.row_map);
+    (void)hipFree(m->lt.pass);
+    (void)hipFree(m->lt.work);
+    (void)hipFree(m->lt.tcol);
+    (void)hipFree(m->lt.tkey);
+    (void)hipFree(m->lt.tval);
+    (void)hipFree(m->lt.slab);
     (void)hipFree(m->interior_ids);
     (void)hipFree(m->boundary_ids);
     (void)hipFree(m->tile_block_pass);
@@ -788,6 +888,9 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->tile_entries = m->tile_entries;
     out->tile_staged_entries = m->tile_staged;
     out->tile_split_rows = m->tile_num_long;
+    out->tile_long_rows = m->lt.rows;
+    out->tile_long_entries = m->lt.entries;
+    out->tile_long_items = m->lt.items;
     out->stream_kernel = m->local_blocks > 0 ? 1 : m->tile_blocks > 0 ? 3
                          : ((m->stream_cap == 4096 || m->stream_cap == 2048) && m->M_local > 0 &&
                             m->nz < (long long)m->M_local * (m->stream_cap / kBlock)) ? 2 : 0;
@@ -795,8 +898,9 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
         out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
                             4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
     else if (m->tile_blocks > 0)  // tiles: 4-byte column + 2-byte key + value per (padded) entry; rows beyond the limit as CSR
-        out->stream_bytes = m->tile_padded * (vb + 6) + 16LL * m->tile_passes + 4LL * m->tile_blocks +
-                            (m->nz - m->tile_entries) * (vb + 4) + 16LL * m->tile_num_pieces +
+        out->stream_bytes = (m->tile_padded + m->lt.padded) * (vb + 6) + 16LL * (m->tile_passes + m->lt.passes) +
+                            4LL * m->tile_blocks + 2 * vb * (long long)m->lt.items * m->lt.rows_per_block +
+                            (m->nz - m->tile_entries - m->lt.entries) * (vb + 4) + 16LL * m->tile_num_pieces +
                             vb * m->M_local + vb * m->N;
     return 0;
 }
@@ -896,14 +1000,37 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                         lds_allowed[which] = lds;
                     }
 #define SPMV_TILE(NT, CH, TRIPS)                                                                                       \
-    hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s, m->tile_blocks,   \
-                       m->tile_rows, stage_ok, g_tile_probe, m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey,         \
-                       (const T *)m->tval, x, y)
+    hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s,      \
+                       m->tile_blocks, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,        \
+                       m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval, x, y)
                     if (which == 0) SPMV_TILE(false, 2048, kTileTrips);
                     else if (which == 1) SPMV_TILE(true, 2048, kTileTrips);
                     else if (which == 2) SPMV_TILE(false, 4096, kTileTrips);
                     else SPMV_TILE(true, 4096, kTileTrips);
 #undef SPMV_TILE
+                    if (m->lt.items > 0) {
+                        // the long rows' own tiles: work items -> slabs -> y (after the ordinary tiles wrote 0 there)
+                        const auto &L = m->lt;
+                        const size_t llds = (size_t)kTileSlotBytes + (size_t)L.rows_per_block * sizeof(T) +
+                                            (stage_ok ? (size_t)L.max_win * sizeof(T) : 0);
+                        if (llds > lds_allowed[which]) {
+                            HIP_TRY(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+                            lds_allowed[which] = llds;
+                        }
+#define SPMV_LTILE(NT, CH, TRIPS)                                                                                      \
+    hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((L.items + 7) / 8 * 8), dim3(kTileBlock), llds, s, L.items,   \
+                       L.rows_per_block, stage_ok, g_tile_probe, (const int4 *)L.work, (T *)L.slab, L.block_row,        \
+                       L.block_pass, L.pass, L.tcol, L.tkey, (const T *)L.tval, x, y)
+                        if (which == 0) SPMV_LTILE(false, 2048, kTileTrips);
+                        else if (which == 1) SPMV_LTILE(true, 2048, kTileTrips);
+                        else if (which == 2) SPMV_LTILE(false, 4096, kTileTrips);
+                        else SPMV_LTILE(true, 4096, kTileTrips);
+#undef SPMV_LTILE
+                        hipLaunchKernelGGL((tile_slab_finish<T>), dim3((L.rows + kFinishRows - 1) / kFinishRows),
+                                           dim3(kFinishRows * kFinishGroups), 0, s, L.rows,
+                                           L.rows_per_block, L.block_row, L.block_of_row, L.item_first, L.row_map,
+                                           (const T *)L.slab, y);
+                    }
                     if (m->tile_num_long) {  // rows beyond the tile limit: stripe-ordered pieces, slots added row by row
                         hipLaunchKernelGGL((csr_long_pieces<T, true>), dim3(m->tile_num_pieces), dim3(kBlock), 0, s,
                                            m->tile_num_pieces, m->tile_pieces, m->col, (const T *)m->val, x, (T *)m->partial);

@@ -130,6 +130,24 @@ long long hll_offsets(int total_rows, const std::vector<int> &mz, std::vector<lo
 }
 
 // workgroup windows, small arrays and vectors of a handle whose JA / AS are already on the device
+// row_seg[r] = (first slot of row r relative to its window's even base) | (slots of the row << 16), for the
+// rows of the x-window plan's windows: what hll_lds_local's row-sum phase needs, in one word.
+__global__ __launch_bounds__(kBlock) void hll_row_segments(int num_blocks, const int4 *__restrict__ desc,
+                                                           const long long *__restrict__ hack_off,
+                                                           const int *__restrict__ maxnz,
+                                                           unsigned *__restrict__ row_seg) {
+    const int b = blockIdx.x;
+    if (b >= num_blocks) return;
+    const int4 d = desc[b];
+    const long long base = (((long long)d.w << 32) | (unsigned)d.z) & ~1LL;
+    for (int q = threadIdx.x; q < d.y; q += kBlock) {
+        const int r = d.x + q, h = r / kHack;
+        const int m = maxnz[h];
+        const long long lo = hack_off[h] + (long long)(r % kHack) * m - base;
+        row_seg[r] = (unsigned)lo | ((unsigned)m << 16);
+    }
+}
+
 // row_seg for the rows of the x-window plan's windows (hack tables and window descriptors are on the device)
 int hll_fill_row_segments(spmv_hll_dev *m) {
     HIP_TRY(hipMalloc((void **)&m->row_seg, std::max<size_t>((size_t)m->M, 1) * sizeof(unsigned)));

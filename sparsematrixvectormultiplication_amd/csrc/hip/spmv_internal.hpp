@@ -51,6 +51,7 @@ extern int g_tile_lmax;       // rows longer than this stay with the split-row k
 extern int g_tile_chunk;      // entries per pass: 0 = auto, 2048 (two workgroups per CU) or 4096 (one)
 extern int g_tile_probe;      // measurement only: bit 0 no LDS staging, bit 1 no gathers, bit 2 no run sums (y is then wrong)
 extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keeps the workgroups in step), 0: equal row counts
+extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile plan of their own (compacted rows, work items, slabs)
 extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
 extern int g_num_cus;
 extern int g_probe_mask;      // csr_probe: table size - 1 (entries) of the folded gather
@@ -152,6 +153,17 @@ struct spmv_csr_dev {
     int *tcol = nullptr;              // [tile_padded + kTileChunkMax]
     unsigned short *tkey = nullptr;
     void *tval = nullptr;
+    // long-row tile plan: the rows beyond the tile limit, compacted into their own row blocks; a block's passes
+    // are dealt out to several workgroups (work items), each leaves its accumulators in a slab
+    struct long_tiles {
+        int blocks = 0, rows = 0, rows_per_block = 0, passes = 0, items = 0, max_win = 0;
+        long long entries = 0, padded = 0, staged = 0;
+        int *block_row = nullptr, *block_pass = nullptr, *block_of_row = nullptr, *item_first = nullptr, *row_map = nullptr;
+        int4 *pass = nullptr, *work = nullptr;
+        int *tcol = nullptr;
+        unsigned short *tkey = nullptr;
+        void *tval = nullptr, *slab = nullptr;
+    } lt;
     int4 *tile_long_rows = nullptr;   // rows beyond the tile limit {row, first slot, pieces, 0} ...
     int4 *tile_pieces = nullptr;      // ... and their pieces, cut at column stripes, stripe by stripe
     int tile_num_long = 0, tile_num_pieces = 0;

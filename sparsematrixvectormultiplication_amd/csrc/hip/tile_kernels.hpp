@@ -237,6 +237,7 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
 template <typename T, bool NT, int CH, int TRIPS>
 __global__ __launch_bounds__(kTileBlock, CH == 2048 ? 4 : 2) void csr_tile(int num_blocks, int rows_per_block,
                                                                           int stage_ok, int probe,
+                                                                          const int4 *__restrict__ work, T *__restrict__ slab,
                                                                           const int *__restrict__ block_row,
                                                                           const int *__restrict__ block_pass,
                                                                           const int4 *__restrict__ pass_desc,
@@ -256,12 +257,26 @@ __global__ __launch_bounds__(kTileBlock, CH == 2048 ? 4 : 2) void csr_tile(int n
     // workgroup ids go round-robin over the 8 XCDs: give every XCD one contiguous eighth of the row blocks, in
     // order, so that neighbouring blocks -- whose x slices overlap -- find each other's lines in the same L2
     const int per_xcd = (num_blocks + 7) >> 3;
-    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || b >= num_blocks) return;
+    const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || id >= num_blocks) return;
     const int t = threadIdx.x;
+    // work (optional): the row blocks' passes dealt out to SEVERAL workgroups each -- {block, first pass, end pass,
+    // slab}: a block of a few very long rows has far more passes than one workgroup should walk; every workgroup
+    // then leaves its accumulators in its own slab and tile_slab_finish adds a row's slabs in order
+    int b = id, p0, p1;
+    T *out = nullptr;
+    if (work) {
+        const int4 w = work[id];
+        b = w.x;
+        p0 = w.y;
+        p1 = w.z;
+        out = slab + (size_t)w.w * rows_per_block;
+    } else {
+        p0 = block_pass[b];
+        p1 = block_pass[b + 1];
+    }
     const int row0 = block_row[b];
     const int nrows = block_row[b + 1] - row0;  // <= rows_per_block
-    const int p0 = block_pass[b], p1 = block_pass[b + 1];
     for (int i = t; i < rows_per_block; i += kTileBlock) acc[i] = T(0);
     if (p0 < p1) {
         // entries: four rotating register sets (the current pass + kTileAhead = 3 in flight), x slices: two
@@ -287,7 +302,42 @@ __global__ __launch_bounds__(kTileBlock, CH == 2048 ? 4 : 2) void csr_tile(int n
 #undef SPMV_TILE_PASS
     }
     __syncthreads();
-    for (int i = t; i < nrows; i += kTileBlock) y[row0 + i] = acc[i];
+    if (out) {
+        for (int i = t; i < nrows; i += kTileBlock) out[i] = acc[i];
+    } else {
+        for (int i = t; i < nrows; i += kTileBlock) y[row0 + i] = acc[i];
+    }
+}
+
+// y[row_map[v]] = the sum of the slabs of virtual row v's block (long-row plans), in a fixed order: the block's
+// work items are cut into kFinishGroups contiguous groups, a thread adds one group's slabs in item order (loads
+// independent of each other: several in flight), then the groups' sums are added in group order.
+constexpr int kFinishRows = 64, kFinishGroups = 16;
+template <typename T>
+__global__ __launch_bounds__(kFinishRows *kFinishGroups) void tile_slab_finish(
+    int rows, int rows_per_block, const int *__restrict__ block_row, const int *__restrict__ block_of_row,
+    const int *__restrict__ item_first, const int *__restrict__ row_map, const T *__restrict__ slab, T *__restrict__ y) {
+    __shared__ T part[kFinishGroups][kFinishRows];
+    const int lane = threadIdx.x % kFinishRows, g = threadIdx.x / kFinishRows;
+    const int v = blockIdx.x * kFinishRows + lane;
+    T s = T(0);
+    if (v < rows) {
+        const int b = block_of_row[v];
+        const int local = v - block_row[b];
+        const int w0 = item_first[b], n = item_first[b + 1] - w0;
+        const int lo = w0 + (int)((long long)n * g / kFinishGroups), hi = w0 + (int)((long long)n * (g + 1) / kFinishGroups);
+        const T *col = slab + local;
+#pragma unroll 4
+        for (int w = lo; w < hi; ++w) s += col[(size_t)w * rows_per_block];
+    }
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && v < rows) {
+        T total = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < kFinishGroups; ++k) total += part[k][lane];
+        y[row_map[v]] = total;
+    }
 }
 #undef SPMV_TILE_ENTRY_REGS
 #undef SPMV_TILE_ENTRY_ARGS

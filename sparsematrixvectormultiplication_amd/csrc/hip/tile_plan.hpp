@@ -5,7 +5,10 @@
 //               about equally many entries each (`balance`: a block closes once it holds the mean number of
 //               entries of a full-height block) -- workgroups that take equally long stay in step on their
 //               way up the columns, which is what keeps the band of x they gather from inside L2
-//   long rows   (more than lmax < 2^17 entries) are left out: `split` marks them for the split-row kernels
+//   rows        are given as (first entry, length) pairs, so that a plan can also be built over a COMPACTED set of
+//               rows (the long rows of a matrix, see spmv_csr.hip); pos_bits = bits of a row's length, the rest of 32
+//               bits numbers the rows of a block (17 / 15 for ordinary plans, 21 / 11 for long-row plans)
+//   long rows   (more than lmax < 2^pos_bits entries) are left out: `split` marks them
 //   per block   its entries ordered by column are cut greedily into passes: a pass takes entries while
 //               it has fewer than kTileChunkMax and -- as long as that keeps it dense enough to be worth
 //               staging -- while its column range fits the LDS window; inside a pass entries are
@@ -57,25 +60,56 @@ struct Part {  // what one builder thread produced for its range of blocks
     int max_win = 0;
 };
 
+// std::sort of 64-bit keys whose top 32 bits are < key_top, with several threads: bucket by the leading bits
+// (two passes), sort the buckets independently.  Used for the few, very large blocks of a long-row plan.
+inline void sort_keys(std::vector<uint64_t> &keys, uint32_t key_top, int threads) {
+    const size_t n = keys.size();
+    if (threads <= 1 || n < (size_t)1 << 22) {
+        std::sort(keys.begin(), keys.end());
+        return;
+    }
+    constexpr int kBuckets = 1024;
+    int shift = 0;
+    while (((uint64_t)key_top >> shift) >= (uint64_t)kBuckets) ++shift;  // bucket = (key >> 32) >> shift < kBuckets
+    std::vector<size_t> start((size_t)kBuckets + 1, 0);
+    for (uint64_t k : keys) ++start[(size_t)((k >> 32) >> shift) + 1];
+    for (int b = 0; b < kBuckets; ++b) start[(size_t)b + 1] += start[(size_t)b];
+    std::vector<uint64_t> tmp(n);
+    {
+        std::vector<size_t> at(start.begin(), start.end() - 1);
+        for (uint64_t k : keys) tmp[at[(size_t)((k >> 32) >> shift)]++] = k;
+    }
+    std::vector<std::thread> pool;
+    for (int th = 0; th < threads; ++th)
+        pool.emplace_back([&, th] {
+            for (int b = th; b < kBuckets; b += threads) std::sort(tmp.begin() + (long)start[(size_t)b], tmp.begin() + (long)start[(size_t)b + 1]);
+        });
+    for (auto &th : pool) th.join();
+    keys.swap(tmp);
+}
+
 template <typename T>
-void build_range(int b0, int b1, const int *block_row, const int *rp, const int *col, const T *val, int lmax,
-                 int chunk, int win_cols, int density, Part<T> &out) {
-    std::vector<uint64_t> keyed;  // column << 32 | local row << 17 | position inside the row (rows <= lmax < 2^17)
+void build_range(int b0, int b1, const int *block_row, const int *row_begin, const int *row_len, const int *col,
+                 const T *val, int lmax, int pos_bits, int chunk, int win_cols, int density, int inner_threads,
+                 uint32_t col_top, Part<T> &out) {
+    // column << 32 | local row << pos_bits | position inside the row (rows <= lmax < 2^pos_bits, local rows < 2^(32 - pos_bits))
+    std::vector<uint64_t> keyed;
+    const uint32_t pos_mask = (1u << pos_bits) - 1;
     std::vector<uint64_t> pass;
     for (int b = b0; b < b1; ++b) {
         const int r0 = block_row[b], r1 = block_row[b + 1];
         keyed.clear();
         for (int r = r0; r < r1; ++r) {
-            const int len = rp[r + 1] - rp[r];
+            const int len = row_len[r];
             if (len > lmax) continue;
             for (int k = 0; k < len; ++k)
-                keyed.push_back(((uint64_t)(unsigned)col[rp[r] + k] << 32) | ((uint64_t)(r - r0) << 17) | (uint64_t)k);
+                keyed.push_back(((uint64_t)(unsigned)col[row_begin[r] + k] << 32) | ((uint64_t)(r - r0) << pos_bits) | (uint64_t)k);
         }
         const size_t n = keyed.size();
         // one pass in CSR order when everything fits: no sort needed to cut, (row, column) is the input order
         bool sorted_by_col = false;
         if (n > (size_t)chunk) {
-            std::sort(keyed.begin(), keyed.end());
+            sort_keys(keyed, col_top, inner_threads);
             sorted_by_col = true;
         }
         int passes = 0;
@@ -112,8 +146,8 @@ void build_range(int b0, int b1, const int *block_row, const int *rp, const int 
             const int e_first = (int)out.tcol.size();
             int prev_row = -1;
             for (uint64_t k : pass) {
-                const int lrow = (int)((k >> 17) & 0x7fff), pos = (int)(k & 0x1ffff);
-                const int e = rp[r0 + lrow] + pos;
+                const int lrow = (int)((uint32_t)k >> pos_bits), pos = (int)((uint32_t)k & pos_mask);
+                const int e = row_begin[r0 + lrow] + pos;
                 out.tcol.push_back(col[e]);
                 out.tval.push_back(val[e]);
                 out.tkey.push_back((unsigned short)(lrow | (lrow != prev_row ? kTileHead : 0)));
@@ -142,9 +176,8 @@ void build_range(int b0, int b1, const int *block_row, const int *rp, const int 
 
 // false: the tiles would not hold the matrix (entry offsets beyond 32 bits)
 template <typename T>
-bool tile_build(int M, int N, const int *rp, const int *col, const T *val, int rows_per_block, int lmax, int density,
-                int chunk, bool balance, TilePlan<T> &plan) {
-    (void)N;
+bool tile_build(int M, int N, const int *row_begin, const int *row_len, const int *col, const T *val, int rows_per_block,
+                int lmax, int density, int chunk, bool balance, int pos_bits, TilePlan<T> &plan) {
     // the window a pass may stage: kTileTrips trips of the workgroup = 40 KiB, which with a 2048-entry chunk and
     // 2048 fp64 accumulators lets two workgroups share a CU's LDS, and with 8192 of them still fits one
     const int win_cols = kTileTrips * kTileTripBytes / (int)sizeof(T);
@@ -155,8 +188,8 @@ bool tile_build(int M, int N, const int *rp, const int *col, const T *val, int r
     plan.split.assign((size_t)M, 0);
     long long in_tiles = 0;
     for (int r = 0; r < M; ++r) {
-        plan.split[r] = rp[r + 1] - rp[r] > lmax;
-        if (!plan.split[r]) in_tiles += rp[r + 1] - rp[r];
+        plan.split[r] = row_len[r] > lmax;
+        if (!plan.split[r]) in_tiles += row_len[r];
     }
     // block boundaries: the row cap, and (balance) the mean entry count of a full-height block
     const long long full_blocks = std::max(1, (M + rows_per_block - 1) / rows_per_block);
@@ -165,7 +198,7 @@ bool tile_build(int M, int N, const int *rp, const int *col, const T *val, int r
     {
         long long held = 0;
         for (int r = 0; r < M; ++r) {
-            const int len = plan.split[r] ? 0 : rp[r + 1] - rp[r];
+            const int len = plan.split[r] ? 0 : row_len[r];
             if (r - plan.block_row.back() == rows_per_block || (held >= target && r > plan.block_row.back())) {
                 plan.block_row.push_back(r);
                 held = 0;
@@ -177,22 +210,27 @@ bool tile_build(int M, int N, const int *rp, const int *col, const T *val, int r
     plan.num_blocks = (int)plan.block_row.size() - 1;
     const int B = plan.num_blocks;
     int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    threads = std::max(1, std::min(threads, B / 4));
+    const int hw_threads = threads;
+    threads = std::max(1, std::min(threads, B >= 64 ? B / 4 : B));
+    const int inner_threads = std::max(1, hw_threads / threads);  // few, large blocks: threads inside the sort instead
     std::vector<tile_detail::Part<T>> parts((size_t)threads);
     // blocks are dealt out in contiguous ranges balanced by entries
     std::vector<int> cut((size_t)threads + 1, B);
     cut[0] = 0;
     {
-        const long long total = rp[M];
-        int th = 1;
-        for (int b = 0; b < B && th < threads; ++b)
-            if ((long long)rp[plan.block_row[(size_t)b + 1]] * threads >= total * th) cut[th++] = b + 1;
+        long long total = 0, run = 0;
+        for (int r = 0; r < M; ++r) total += row_len[r];
+        int th = 1, r = 0;
+        for (int b = 0; b < B && th < threads; ++b) {
+            for (; r < plan.block_row[(size_t)b + 1]; ++r) run += row_len[r];
+            if (run * threads >= total * th) cut[th++] = b + 1;
+        }
     }
     std::vector<std::thread> pool;
     for (int th = 0; th < threads; ++th)
         pool.emplace_back([&, th] {
-            tile_detail::build_range<T>(cut[th], cut[th + 1], plan.block_row.data(), rp, col, val, lmax, chunk, win_cols,
-                                        density, parts[th]);
+            tile_detail::build_range<T>(cut[th], cut[th + 1], plan.block_row.data(), row_begin, row_len, col, val, lmax,
+                                        pos_bits, chunk, win_cols, density, inner_threads, (uint32_t)std::max(N, 1), parts[th]);
         });
     for (auto &th : pool) th.join();
     size_t total_entries = 0, total_passes = 0;

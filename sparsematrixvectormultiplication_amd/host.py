@@ -258,7 +258,7 @@ def csr_plan_check(M, N, row_ptr, col_idx, value_bytes=8):
                     (int(v) for v in stats)))
 
 
-def csr_tile_plan_check(M, N, row_ptr, col_idx, value_bytes=8, rows_per_block=2048, lmax=16384, density=16, chunk=2048,
+def csr_tile_plan_check(M, N, row_ptr, col_idx, value_bytes=8, rows_per_block=2048, lmax=1024, density=16, chunk=2048,
                         balance=True):
     """Host-only self-check of the csr_tile plan (spmv_hip_csr_tile_plan_check); returns its stats."""
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)

@@ -117,7 +117,9 @@ def test_c5_powerlaw_fp32_full_size_properties(gpu, oracle):
 
     with sp.CsrDevice(n, n, row_ptr, col, val) as dev:
         info = dev.info()
-        assert info["stream_kernel"] == 3 and info["tile_entries"] + 0 < info["nz"]   # csr_tile + split rows
+        assert info["stream_kernel"] == 3 and info["tile_entries"] < info["nz"]       # csr_tile ...
+        assert info["tile_entries"] + info["tile_long_entries"] == info["nz"]          # ... + the long rows' tiles
+        assert info["tile_long_rows"] > 1000 and info["tile_split_rows"] == 0
         y1 = dev.spmv(x1, sp.CSR_AUTO)
         sample_check(y1, x1, "powerlaw full size")
         assert dev.spmv(x1, sp.CSR_AUTO).tobytes() == y1.tobytes()      # no atomics: same bits every launch

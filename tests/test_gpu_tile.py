@@ -36,8 +36,8 @@ class tuned:
             set_tuning(k, v)
 
     def __exit__(self, *exc):
-        defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 16384, "tile_density": 16, "stream_kind": -1,
-                    "tile_balance": 1, "tile_chunk": 0}
+        defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 16, "stream_kind": -1,
+                    "tile_balance": 1, "tile_chunk": 0, "tile_long": 1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 
@@ -117,13 +117,17 @@ def test_tile_kernel_skewed_rows_sub_runs_and_split_rows(gpu, oracle, dtype):
     rp, col, val = scattered(rng, M, N, 0, dtype=dtype, lens=lens)
     x = rng.uniform(-1, 1, N).astype(dtype)
     y_ref = reference(oracle, rp, col, val, x, dtype)
-    for lmax, balance in ((16384, 1), (700, 1), (700, 0), (40, 1)):
-        with tuned(stream_tile=1, tile_rows=512, tile_lmax=lmax, tile_balance=balance):
+    for lmax, balance, long_plan in ((16384, 1, 0), (700, 1, 0), (700, 0, 2), (40, 1, 2), (16384, 1, 2)):
+        with tuned(stream_tile=1, tile_rows=512, tile_lmax=lmax, tile_balance=balance, tile_long=long_plan):
             with sp.CsrDevice(M, N, rp, col, val) as dev:
                 info = dev.info()
-                assert info["stream_kernel"] == 3 and info["tile_split_rows"] == int((lens > lmax).sum()) > 0
-                assert info["tile_entries"] == int(lens[lens <= lmax].sum())
-                check(dev, x, y_ref, rp, col, val, dtype, f"skewed lmax={lmax} balance={balance}")
+                assert info["stream_kernel"] == 3 and info["tile_entries"] == int(lens[lens <= lmax].sum())
+                if long_plan:    # the rows beyond the limit: their own tiles (work items + slabs), nothing left over
+                    assert info["tile_long_rows"] == int((lens > lmax).sum()) > 0 and info["tile_split_rows"] == 0
+                    assert info["tile_long_entries"] == int(lens[lens > lmax].sum()) and info["tile_long_items"] >= 1
+                else:            # ... or the split-row kernels
+                    assert info["tile_split_rows"] == int((lens > lmax).sum()) > 0 and info["tile_long_rows"] == 0
+                check(dev, x, y_ref, rp, col, val, dtype, f"skewed lmax={lmax} balance={balance} long={long_plan}")
 
 
 def test_tile_kernel_row_block_handle_and_foreign_x(gpu, oracle):

@@ -37,20 +37,24 @@ def bench_line(log):
     raise SystemExit(f"no bench JSON line in {log}")
 
 
-def mean_counter(sub, counter):
-    acc = defaultdict(list)
+def per_product(sub, counter, products):
+    """Counter value per SpMV: the sum over ALL dispatches of a kernel name divided by the number of products the
+    profiled bench ran (a kernel that is launched twice per product -- csr_tile: ordinary tiles + long rows' tiles --
+    must be added up, not averaged)."""
+    acc = defaultdict(float)
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
-                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+                acc[row["Kernel_Name"]] += float(row["Counter_Value"])
+    return {k: v / products for k, v in acc.items()}
 
 
 line = bench_line(os.path.join(root, "trace.log"))
 kernel = line["roofline"]["kernel"]
 workload = line["config"]["workload_key"]
-fetch = mean_counter("pmc_fetch", "FETCH_SIZE")
-write = mean_counter("pmc_write", "WRITE_SIZE")
+products = int(line["steps"]) + int(line["warmup"]) + 1   # bench.py at N = 1: W warm-ups + 1, then the K timed steps
+fetch = per_product("pmc_fetch", "FETCH_SIZE", products)
+write = per_product("pmc_write", "WRITE_SIZE", products)
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 table = json.load(open(out_path)) if os.path.exists(out_path) else {}
 table = {k: v for k, v in table.items() if isinstance(v, dict)}  # round-1 entries carried no stamp
