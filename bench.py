@@ -333,6 +333,7 @@ def cpu_baseline_hll(wl, cpu_iters):
 
 # ----------------------------------------------------------------- side measurements
 def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
+    from sparsematrixvectormultiplication_amd.device import HLL_LDS_KERNELS
     """cant-like CSR / HLL on this GPU (BASELINE configs[1], [2]) and the same FEM-shaped
     generator scaled past the Infinity Cache; kernel-only event times."""
     if which == "fem_large_csr":
@@ -348,7 +349,7 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
                 hdev.set_x(np.ones(M))
                 hinfo = hdev.info()
                 hms = hdev.time(sp.HLL_LDS, warmup, steps, zero_y=True)
-            hll = {"kernel": "hll_lds_local" if hinfo["local_blocks"] else "hll_lds", "slots": hinfo["slots"],
+            hll = {"kernel": HLL_LDS_KERNELS[hinfo["stream_kernel"]], "slots": hinfo["slots"],
                    "algo_bytes": hinfo["algo_bytes"], "format_bytes": hinfo["stream_bytes"] or hinfo["algo_bytes"],
                    "gflops": round(2.0 * nnz / (hms.mean() * 1e-3) / 1e9, 1),
                    "gbps": round(hinfo["algo_bytes"] / (hms.mean() * 1e-3) / 1e9, 1),

@@ -61,7 +61,8 @@ enum {
     SPMV_HLL_THREAD_ROW = 1, /* one lane per row over the row-major slab (spmv_hll_naive_kernel) */
     SPMV_HLL_SUBWAVE = 2,    /* a lane group per row                     (spmv_hll_warp_kernel) */
     SPMV_HLL_LDS = 3         /* row-aligned slab windows staged through LDS (spmv_hll_warp_shared_kernel_v1's
-                                slot): hll_lds_local with an x-window plan, else hll_lds; what AUTO resolves to */
+                                slot): hll_lds_local with an x-window plan; for a large slab with scattered columns
+                                the 2-D tile kernel over the slab's rows; else hll_lds; what AUTO resolves to */
 };
 
 typedef struct {
@@ -87,7 +88,7 @@ typedef struct {
                               0 without a plan (then algo_bytes is what moves)    */
     int stream_kernel;     /* which kernel STREAM / LDS (and AUTO) launches with default tuning:
                               CSR 0 csr_stream, 1 csr_stream_local, 2 csr_stream_short, 3 csr_tile;
-                              HLL 0 hll_lds, 1 hll_lds_local */
+                              HLL 0 hll_lds, 1 hll_lds_local, 2 csr_tile over the slab's rows (padding slots included) */
     int tile_blocks;       /* CSR: row blocks (workgroups) of csr_tile, 0 = no tile plan */
     int tile_passes;       /* CSR: column passes over all blocks */
     int tile_split_rows;   /* CSR: rows beyond the tile limit (split-row kernels, stripe-ordered pieces) */

@@ -192,10 +192,10 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
                 M, N, nz, hi.slots, ci.algo_bytes, hi.algo_bytes, r_stream.time,
                 r_stream.flops / 1e9, gb_c, gb_c / 80.0, r_stream.err.mean_rel_err, h_lds.time,
                 h_lds.flops / 1e9, gb_h, gb_h / 80.0,
-                ci.stream_kernel == 1 ? "csr_stream_local" : (ci.stream_kernel == 2 ? "csr_stream_short" : "csr_stream"),
-                ci.local_blocks > 0 ? ci.stream_bytes : ci.algo_bytes,
-                hi.local_blocks > 0 ? "hll_lds_local" : "hll_lds",
-                hi.local_blocks > 0 ? hi.stream_bytes : hi.algo_bytes);
+                ci.stream_kernel == 1 ? "csr_stream_local" : (ci.stream_kernel == 2 ? "csr_stream_short" : (ci.stream_kernel == 3 ? "csr_tile" : "csr_stream")),
+                ci.stream_bytes > 0 ? ci.stream_bytes : ci.algo_bytes,
+                hi.stream_kernel == 1 ? "hll_lds_local" : (hi.stream_kernel == 2 ? "csr_tile(hll)" : "hll_lds"),
+                hi.stream_bytes > 0 ? hi.stream_bytes : hi.algo_bytes);
         fclose(fp);
     }
     /* launch shapes (reference: write_block_result_to_csv, cuda_src/utility.cu:236-261, called at
@@ -214,9 +214,9 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
                   "hll_lanes_per_row_subwave,hll_lds_kernel,hll_lds_workgroups,hll_xwindow_workgroups,"
                   "hll_xwindow_stage_lines\n", fp);
         fprintf(fp, "%s,%d,256,%d,%s,%d,%d,%d,%d,%d,%s,%d,%d,%d\n", name, nz, ci.lanes_per_row,
-                ci.stream_kernel == 1 ? "csr_stream_local" : (ci.stream_kernel == 2 ? "csr_stream_short" : "csr_stream"),
+                ci.stream_kernel == 1 ? "csr_stream_local" : (ci.stream_kernel == 2 ? "csr_stream_short" : (ci.stream_kernel == 3 ? "csr_tile" : "csr_stream")),
                 ci.stream_blocks, ci.local_blocks, ci.local_stage_lines, ci.long_rows, hi.lanes_per_row,
-                hi.local_blocks > 0 ? "hll_lds_local" : "hll_lds", hi.stream_blocks, hi.local_blocks,
+                hi.stream_kernel == 1 ? "hll_lds_local" : (hi.stream_kernel == 2 ? "csr_tile(hll)" : "hll_lds"), hi.stream_blocks, hi.local_blocks,
                 hi.local_stage_lines);
         fclose(fp);
     }

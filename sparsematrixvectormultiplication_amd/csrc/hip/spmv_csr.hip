@@ -114,6 +114,144 @@ bool build_long_tiles(int M, int N, const int *rp, const int *row_len, const int
     return true;
 }
 
+// Everything the tile plans of one handle consist of on the host, between planning and upload.
+template <typename T>
+struct TileBuild {
+    TilePlan<T> tiles, ltiles;
+    bool have_tiles = false, have_long_tiles = false, scattered = false;
+    std::vector<int4> tile_pieces, tile_long, lt_work;
+    std::vector<int> lt_rows, lt_item_first;
+};
+
+// The tile plans for rows given as (first entry, length) pairs over host arrays col / val -- a CSR matrix's rows, or
+// the rows of an HLL slab (spmv_hll.hip).  rp: the CSR row pointer when the rows ARE a CSR matrix's (then rows that
+// neither plan takes go to stripe-cut split-row pieces), nullptr otherwise (then such rows veto the plan).
+//
+// Rows per block (auto): two regimes, told apart on a sample of the rows.
+//  * banded (most entries in passes that can be staged): 32 KiB of accumulators (4096 fp64 / 8192 fp32 rows), so
+//    that two workgroups with their 40 KiB x slices share a CU (road-like, wide band: measured best of 2048 / 4096 /
+//    8192);
+//  * scattered (gather passes): what matters is that a pass spans little of x (the band all blocks gather from
+//    together must fit L2), that the blocks run in few rounds (a new round starts again at column 0) and that not
+//    too many of them are on the way at once: the tallest blocks (up to 16384 rows) that still leave ~2 per CU, ONE
+//    workgroup per CU.  Power-law matrix (fp32, 2^24 rows): 2.90 ms at 8192 rows, 1.97 ms at 16384 with one
+//    workgroup per CU, 2.39 ms with two.
+template <typename T>
+void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, const int *rp, long long nz, const int *hcol,
+                   const T *hval, TileBuild<T> &tb) {
+    const int chunk = g_tile_chunk ? g_tile_chunk : 2048;
+    int rb = g_tile_rows;
+    const int density = g_tile_density;
+    if (!rb) {
+        const int banded_rows = 32768 / (int)sizeof(T);
+        // a slice of the matrix from its middle (rows keep their global columns)
+        const int sample = std::min(Ml, 8 * banded_rows), s0 = (Ml - sample) / 2;
+        TilePlan<T> probe;
+        const bool ok = tile_build<T>(sample, N, row_begin + s0, row_len + s0, hcol, hval, banded_rows, g_tile_lmax, density,
+                                      chunk, g_tile_balance != 0, 17, probe);
+        if (ok && probe.staged_entries * 2 >= probe.entries) {
+            rb = banded_rows;
+        } else {
+            rb = 16384;
+            while (rb > 2048 && (long long)Ml < 448LL * rb) rb >>= 1;  // at least ~1.75 blocks per CU
+            tb.scattered = true;
+        }
+    }
+    tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
+                                  g_tile_balance != 0, 17, tb.tiles);
+    // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
+    if (tb.have_tiles && g_stream_tile < 0 && !g_tile_long && tb.tiles.entries * 2 < nz) tb.have_tiles = false;
+    if (!tb.have_tiles) return;
+    // The rows beyond the tile limit, compacted: their own row blocks (<= 2048 of them each), same passes -- so many
+    // entries per column range that every pass is staged: the long rows' x lookups happen in LDS at the HBM streaming
+    // rate instead of going through the gather path -- and a block's passes dealt out to many workgroups.
+    std::vector<unsigned char> leftover = tb.tiles.split;
+    if (g_tile_long)
+        tb.have_long_tiles = build_long_tiles<T>(Ml, N, row_begin, row_len, hcol, hval, chunk, leftover, tb.ltiles, tb.lt_rows,
+                                                 tb.lt_work, tb.lt_item_first);
+    bool any_left = false;
+    for (unsigned char f : leftover) any_left |= f != 0;
+    if (!any_left) return;
+    if (!rp) {  // no CSR arrays on the device to fall back on
+        tb.have_tiles = tb.have_long_tiles = false;
+        return;
+    }
+    // whatever is left (rows of 2^21 entries and more, or all long rows with tile_long = 0) stays with the split-row
+    // kernels, pieces cut at stripes of 1 MiB of x: a quarter of an XCD's L2
+    const int stripe_cols = (1 << 20) / (int)sizeof(T);
+    build_striped_pieces(Ml, rp, hcol, leftover, stripe_cols, tb.tile_pieces, tb.tile_long);
+}
+
+// the plans' arrays -> the handle
+template <typename T>
+int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
+    int rc = 0;
+    if (tb.have_tiles) {
+        const TilePlan<T> &tiles = tb.tiles;
+        rc |= upload_array(&m->tile_block_pass, tiles.block_pass.data(), tiles.block_pass.size(), 1);
+        if (!rc) rc |= upload_array(&m->tile_block_row, tiles.block_row.data(), tiles.block_row.size(), 1);
+        if (!rc) rc |= upload_array(&m->tile_pass, tiles.pass_desc.data(), tiles.pass_desc.size(), 1);
+        if (!rc) rc |= upload_array(&m->tcol, tiles.tcol.data(), tiles.tcol.size(), 0);
+        if (!rc) rc |= upload_array(&m->tkey, tiles.tkey.data(), tiles.tkey.size(), 0);
+        if (!rc) rc |= upload_array((T **)&m->tval, tiles.tval.data(), tiles.tval.size(), 0);
+        if (!rc && !tb.tile_long.empty()) rc |= upload_array(&m->tile_long_rows, tb.tile_long.data(), tb.tile_long.size(), 0);
+        if (!rc && !tb.tile_pieces.empty()) rc |= upload_array(&m->tile_pieces, tb.tile_pieces.data(), tb.tile_pieces.size(), 0);
+        if (!rc) {
+            m->tile_blocks = tiles.num_blocks;
+            m->tile_rows = tiles.rows_per_block;
+            m->tile_chunk = tiles.chunk;
+            m->tile_lds_min = tb.scattered ? 84 * 1024 : 0;  // more than half a CU's LDS: one workgroup per CU
+            m->tile_passes = (int)tiles.pass_desc.size();
+            m->tile_max_win = tiles.max_win;
+            m->tile_entries = tiles.entries;
+            m->tile_staged = tiles.staged_entries;
+            m->tile_staged_cols = tiles.staged_cols;
+            m->tile_padded = (long long)tiles.tcol.size() - kTileChunkMax;
+            m->tile_num_long = (int)tb.tile_long.size();
+            m->tile_num_pieces = (int)tb.tile_pieces.size();
+            m->device_bytes += tiles.tcol.size() * (6 + sizeof(T)) + tiles.pass_desc.size() * 16 + tiles.block_pass.size() * 4 +
+                               (tb.tile_pieces.size() + tb.tile_long.size()) * 16;
+        }
+    }
+    if (!rc && tb.have_long_tiles) {
+        const TilePlan<T> &ltiles = tb.ltiles;
+        auto &L = m->lt;
+        std::vector<int> block_of_row(tb.lt_rows.size());
+        for (int b = 0; b < ltiles.num_blocks; ++b)
+            for (int v = ltiles.block_row[(size_t)b]; v < ltiles.block_row[(size_t)b + 1]; ++v) block_of_row[(size_t)v] = b;
+        rc |= upload_array(&L.block_row, ltiles.block_row.data(), ltiles.block_row.size(), 1);
+        if (!rc) rc |= upload_array(&L.block_pass, ltiles.block_pass.data(), ltiles.block_pass.size(), 1);
+        if (!rc) rc |= upload_array(&L.block_of_row, block_of_row.data(), block_of_row.size(), 1);
+        if (!rc) rc |= upload_array(&L.item_first, tb.lt_item_first.data(), tb.lt_item_first.size(), 1);
+        if (!rc) rc |= upload_array(&L.row_map, tb.lt_rows.data(), tb.lt_rows.size(), 1);
+        if (!rc) rc |= upload_array(&L.pass, ltiles.pass_desc.data(), ltiles.pass_desc.size(), 1);
+        if (!rc) rc |= upload_array(&L.work, tb.lt_work.data(), tb.lt_work.size(), 1);
+        if (!rc) rc |= upload_array(&L.tcol, ltiles.tcol.data(), ltiles.tcol.size(), 0);
+        if (!rc) rc |= upload_array(&L.tkey, ltiles.tkey.data(), ltiles.tkey.size(), 0);
+        if (!rc) rc |= upload_array((T **)&L.tval, ltiles.tval.data(), ltiles.tval.size(), 0);
+        if (!rc) {
+            const size_t slab_bytes = std::max<size_t>(1, tb.lt_work.size()) * (size_t)ltiles.rows_per_block * sizeof(T);
+            hipError_t e = hipMalloc(&L.slab, slab_bytes);
+            if (e != hipSuccess) rc = fail("hipMalloc(slabs) failed: %s", hipGetErrorString(e));
+            m->device_bytes += slab_bytes;
+        }
+        if (!rc) {
+            L.blocks = ltiles.num_blocks;
+            L.rows = (int)tb.lt_rows.size();
+            L.rows_per_block = ltiles.rows_per_block;
+            L.passes = (int)ltiles.pass_desc.size();
+            L.items = (int)tb.lt_work.size();
+            L.max_win = ltiles.max_win;
+            L.entries = ltiles.entries;
+            L.padded = (long long)ltiles.tcol.size() - kTileChunkMax;
+            L.staged = ltiles.staged_entries;
+            m->device_bytes += ltiles.tcol.size() * (6 + sizeof(T)) + ltiles.pass_desc.size() * 16 + tb.lt_work.size() * 16 +
+                               tb.lt_rows.size() * 8;
+        }
+    }
+    return rc;
+}
+
 bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, int cap, int rows_cap,
                      int line_shift, int lines_max, const std::vector<int4> &baseline, LocalPlan &plan) {
     const int total_lines = (int)(((long long)N + (1 << line_shift) - 1) >> line_shift);
@@ -366,79 +504,27 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     // workgroups sweep x together (L2-resident band), dense passes staged in LDS.  Needs enough row
     // blocks to fill the chip; rows longer than tile_lmax stay with the split-row kernels, their
     // pieces cut at column stripes.
-    TilePlan<T> tiles, ltiles;
-    bool have_tiles = false, scattered = false, have_long_tiles = false;
-    std::vector<int4> tile_pieces, tile_long, lt_work;
-    std::vector<int> lt_rows, lt_item_first;
-    if (!have_local && nz > 0 && g_stream_tile != 0 && g_stream_cap == 0) {
-        // Rows per block (auto): two regimes, told apart on a sample of the rows.
-        //  * banded (most entries in passes that can be staged): 32 KiB of accumulators (4096 fp64 / 8192 fp32
-        //    rows), so that two workgroups with their 40 KiB x slices share a CU (road-like, wide band:
-        //    measured best of 2048 / 4096 / 8192);
-        //  * scattered (gather passes): what matters is that a pass spans little of x (the band all blocks
-        //    gather from together must fit L2), that the blocks run in few rounds (a new round starts again at
-        //    column 0) and that not too many of them are on the way at once: the tallest blocks (up to 16384
-        //    rows) that still leave ~2 per CU, ONE workgroup per CU.  Power-law matrix (fp32, 2^24 rows):
-        //    2.90 ms at 8192 rows, 1.97 ms at 16384 with one workgroup per CU, 2.39 ms with two.
-        const int chunk = g_tile_chunk ? g_tile_chunk : 2048;
-        const bool want = g_stream_tile == 1 || (long long)Ml >= 512LL * 2048;
-        if (want) {
-            std::vector<int> col_copy;
-            std::vector<T> val_copy;
-            const int *hcol = col_idx ? col_idx + e0 : nullptr;
-            const T *hval = values ? values + e0 : nullptr;
-            if (!hcol) {  // adopted arrays live on the device only
-                col_copy.resize((size_t)nz);
-                val_copy.resize((size_t)nz);
-                if (hipMemcpy(col_copy.data(), m->col, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
-                    hipMemcpy(val_copy.data(), m->val, (size_t)nz * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
-                    drop(m);
-                    return fail("csr_upload: copying the matrix back for the tile plan failed");
-                }
-                hcol = col_copy.data();
-                hval = val_copy.data();
+    TileBuild<T> tb;
+    if (!have_local && nz > 0 && g_stream_tile != 0 && g_stream_cap == 0 &&
+        (g_stream_tile == 1 || (long long)Ml >= 512LL * 2048)) {
+        std::vector<int> col_copy;
+        std::vector<T> val_copy;
+        const int *hcol = col_idx ? col_idx + e0 : nullptr;
+        const T *hval = values ? values + e0 : nullptr;
+        if (!hcol) {  // adopted arrays live on the device only
+            col_copy.resize((size_t)nz);
+            val_copy.resize((size_t)nz);
+            if (hipMemcpy(col_copy.data(), m->col, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(val_copy.data(), m->val, (size_t)nz * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
+                drop(m);
+                return fail("csr_upload: copying the matrix back for the tile plan failed");
             }
-            int rb = g_tile_rows;
-            const int density = g_tile_density;
-            if (!rb) {
-                const int banded_rows = 32768 / (int)sizeof(T);
-                // a slice of the matrix from its middle (rows keep their global columns)
-                const int sample = std::min(Ml, 8 * banded_rows), s0 = (Ml - sample) / 2;
-                std::vector<int> srp((size_t)sample + 1);
-                for (int r = 0; r <= sample; ++r) srp[(size_t)r] = rp[(size_t)s0 + r] - rp[(size_t)s0];
-                TilePlan<T> probe;
-                std::vector<int> slen((size_t)sample);
-                for (int r = 0; r < sample; ++r) slen[(size_t)r] = srp[(size_t)r + 1] - srp[(size_t)r];
-                const bool ok = tile_build<T>(sample, N, srp.data(), slen.data(), hcol + rp[(size_t)s0], hval + rp[(size_t)s0],
-                                              banded_rows, g_tile_lmax, density, chunk, g_tile_balance != 0, 17, probe);
-                if (ok && probe.staged_entries * 2 >= probe.entries) {
-                    rb = banded_rows;
-                } else {
-                    rb = 16384;
-                    while (rb > 2048 && (long long)Ml < 448LL * rb) rb >>= 1;  // at least ~1.75 blocks per CU
-                    scattered = true;
-                }
-            }
-            std::vector<int> row_len((size_t)Ml);
-            for (int r = 0; r < Ml; ++r) row_len[(size_t)r] = rp[(size_t)r + 1] - rp[(size_t)r];
-            have_tiles = tile_build<T>(Ml, N, rp.data(), row_len.data(), hcol, hval, rb, g_tile_lmax, density, chunk,
-                                       g_tile_balance != 0, 17, tiles);
-            // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
-            if (have_tiles && g_stream_tile < 0 && !g_tile_long && tiles.entries * 2 < nz) have_tiles = false;
-            if (have_tiles) {
-                // The rows beyond the tile limit, compacted: their own row blocks (<= 2048 of them each), same
-                // passes -- so many entries per column range that every pass is staged: the long rows' x lookups
-                // happen in LDS at the HBM streaming rate instead of going through the gather path -- and a
-                // block's passes dealt out to many workgroups.
-                std::vector<unsigned char> leftover = tiles.split;
-                if (g_tile_long) have_long_tiles = build_long_tiles<T>(Ml, N, rp.data(), row_len.data(), hcol, hval, chunk,
-                                                                        leftover, ltiles, lt_rows, lt_work, lt_item_first);
-                // whatever is left (rows of 2^21 entries and more) stays with the split-row kernels, pieces cut at
-                // stripes of 1 MiB of x: a quarter of an XCD's L2
-                const int stripe_cols = (1 << 20) / (int)sizeof(T);
-                build_striped_pieces(Ml, rp.data(), hcol, leftover, stripe_cols, tile_pieces, tile_long);
-            }
+            hcol = col_copy.data();
+            hval = val_copy.data();
         }
+        std::vector<int> row_len((size_t)Ml);
+        for (int r = 0; r < Ml; ++r) row_len[(size_t)r] = rp[(size_t)r + 1] - rp[(size_t)r];
+        tile_plan_all<T>(Ml, N, rp.data(), row_len.data(), rp.data(), nz, hcol, hval, tb);
     }
     // else: larger stages amortise per-workgroup latency on big matrices; small ones need
     // enough workgroups to fill 256 CUs (measured: cant-like 2048, nlpkkt-like 4096)
@@ -477,66 +563,10 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
     if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
     if (!rc && num_partial) rc |= upload_array(&m->pieces, pieces.data(), pieces.size(), 0);
-    if (!rc && have_tiles) {
-        rc |= upload_array(&m->tile_block_pass, tiles.block_pass.data(), tiles.block_pass.size(), 1);
-        if (!rc) rc |= upload_array(&m->tile_block_row, tiles.block_row.data(), tiles.block_row.size(), 1);
-        if (!rc) rc |= upload_array(&m->tile_pass, tiles.pass_desc.data(), tiles.pass_desc.size(), 1);
-        if (!rc) rc |= upload_array(&m->tcol, tiles.tcol.data(), tiles.tcol.size(), 0);
-        if (!rc) rc |= upload_array(&m->tkey, tiles.tkey.data(), tiles.tkey.size(), 0);
-        if (!rc) rc |= upload_array((T **)&m->tval, tiles.tval.data(), tiles.tval.size(), 0);
-        if (!rc && !tile_long.empty()) rc |= upload_array(&m->tile_long_rows, tile_long.data(), tile_long.size(), 0);
-        if (!rc && !tile_pieces.empty()) rc |= upload_array(&m->tile_pieces, tile_pieces.data(), tile_pieces.size(), 0);
-        if (!rc) {
-            m->tile_blocks = tiles.num_blocks;
-            m->tile_rows = tiles.rows_per_block;
-            m->tile_chunk = tiles.chunk;
-            m->tile_lds_min = scattered ? 84 * 1024 : 0;  // more than half a CU's LDS: one workgroup per CU
-            m->tile_passes = (int)tiles.pass_desc.size();
-            m->tile_max_win = tiles.max_win;
-            m->tile_entries = tiles.entries;
-            m->tile_staged = tiles.staged_entries;
-            m->tile_staged_cols = tiles.staged_cols;
-            m->tile_padded = (long long)tiles.tcol.size() - kTileChunkMax;
-            m->tile_num_long = (int)tile_long.size();
-            m->tile_num_pieces = (int)tile_pieces.size();
-        }
-    }
-    if (!rc && have_long_tiles) {
-        auto &L = m->lt;
-        std::vector<int> block_of_row(lt_rows.size());
-        for (int b = 0; b < ltiles.num_blocks; ++b)
-            for (int v = ltiles.block_row[(size_t)b]; v < ltiles.block_row[(size_t)b + 1]; ++v) block_of_row[(size_t)v] = b;
-        rc |= upload_array(&L.block_row, ltiles.block_row.data(), ltiles.block_row.size(), 1);
-        if (!rc) rc |= upload_array(&L.block_pass, ltiles.block_pass.data(), ltiles.block_pass.size(), 1);
-        if (!rc) rc |= upload_array(&L.block_of_row, block_of_row.data(), block_of_row.size(), 1);
-        if (!rc) rc |= upload_array(&L.item_first, lt_item_first.data(), lt_item_first.size(), 1);
-        if (!rc) rc |= upload_array(&L.row_map, lt_rows.data(), lt_rows.size(), 1);
-        if (!rc) rc |= upload_array(&L.pass, ltiles.pass_desc.data(), ltiles.pass_desc.size(), 1);
-        if (!rc) rc |= upload_array(&L.work, lt_work.data(), lt_work.size(), 1);
-        if (!rc) rc |= upload_array(&L.tcol, ltiles.tcol.data(), ltiles.tcol.size(), 0);
-        if (!rc) rc |= upload_array(&L.tkey, ltiles.tkey.data(), ltiles.tkey.size(), 0);
-        if (!rc) rc |= upload_array((T **)&L.tval, ltiles.tval.data(), ltiles.tval.size(), 0);
-        if (!rc) {
-            const size_t slab_bytes = std::max<size_t>(1, lt_work.size()) * (size_t)ltiles.rows_per_block * sizeof(T);
-            hipError_t e = hipMalloc(&L.slab, slab_bytes);
-            if (e != hipSuccess) rc = fail("hipMalloc(slabs) failed: %s", hipGetErrorString(e));
-            m->device_bytes += slab_bytes;
-        }
-        if (!rc) {
-            L.blocks = ltiles.num_blocks;
-            L.rows = (int)lt_rows.size();
-            L.rows_per_block = ltiles.rows_per_block;
-            L.passes = (int)ltiles.pass_desc.size();
-            L.items = (int)lt_work.size();
-            L.max_win = ltiles.max_win;
-            L.entries = ltiles.entries;
-            L.padded = (long long)ltiles.tcol.size() - kTileChunkMax;
-            L.staged = ltiles.staged_entries;
-            m->device_bytes += ltiles.tcol.size() * (6 + sizeof(T)) + ltiles.pass_desc.size() * 16 + lt_work.size() * 16 +
-                               lt_rows.size() * 8;
-        }
-    }
-    const int partial_slots = std::max(num_partial, (int)tile_pieces.size());
+    const size_t bytes_before_tiles = m->device_bytes;
+    if (!rc) rc |= tile_upload_all<T>(m, tb);
+    const size_t tile_bytes = m->device_bytes - bytes_before_tiles;  // (device_bytes is recomputed below)
+    const int partial_slots = std::max(num_partial, (int)tb.tile_pieces.size());
     if (!rc && partial_slots) {
         hipError_t e = hipMalloc(&m->partial, (size_t)partial_slots * sizeof(T));
         if (e != hipSuccess) rc = fail("hipMalloc(partial) failed: %s", hipGetErrorString(e));
@@ -560,9 +590,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     if (have_local)
         m->device_bytes += (size_t)m->local_blocks * 24 + ((size_t)m->local_lines + kLocalLinesMax) * 4 +
                            ((size_t)nz + kPad) * 2;
-    if (have_tiles)
-        m->device_bytes += tiles.tcol.size() * (6 + sizeof(T)) + tiles.pass_desc.size() * 16 + tiles.block_pass.size() * 4 +
-                           (tile_pieces.size() + tile_long.size()) * 16;
+    m->device_bytes += tile_bytes;
 
     // lanes per row for the SUBWAVE kernel: about half the mean row length,
     // rounded to a power of two, so that a typical row takes 1-2 passes
@@ -809,6 +837,38 @@ int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_v
     return guarded("csr_adopt", [&] { return csr_upload_impl<double>(M, N, row_ptr_host, nullptr, nullptr, 0, M, out, d_col, d_val); });
 }
 
+// A handle that carries NOTHING but tile plans, for rows given as (first entry, length) pairs over host arrays:
+// how an HLL slab whose columns are too scattered for the x-window plan gets csr_tile (spmv_hll.hip).  The rows
+// are rows [row0, row0 + M_local) of a matrix with M_total rows; launched with the caller's x and full-length y.
+// *out stays NULL (return 0) when the rows get no plan.
+int csr_tiles_from_rows_f64(int M_local, int M_total, int row0, int N, const int *row_begin, const int *row_len,
+                            long long entries, const int *col, const double *val, spmv_csr_dev **out) {
+    *out = nullptr;
+    if (M_local <= 0 || entries <= 0 || g_stream_tile == 0) return 0;
+    if (g_stream_tile < 0 && (long long)M_local < 512LL * 2048) return 0;
+    return guarded("hll tile plan", [&] {
+        TileBuild<double> tb;
+        tile_plan_all<double>(M_local, N, row_begin, row_len, nullptr, entries, col, val, tb);
+        if (!tb.have_tiles) return 0;
+        spmv_csr_dev *m = new (std::nothrow) spmv_csr_dev();
+        if (!m) return fail("hll tile plan: out of host memory");
+        m->value_bytes = 8;
+        m->M_local = M_local;
+        m->M_total = M_total;
+        m->N = N;
+        m->row0 = row0;
+        m->nz = entries;
+        m->tiles_only = true;
+        m->auto_variant = SPMV_CSR_STREAM;
+        if (tile_upload_all<double>(m, tb)) {
+            spmv_hip_csr_free(m);
+            return -1;
+        }
+        *out = m;
+        return 0;
+    });
+}
+
 extern "C" int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
                                    const double *values, int row0, int row1, spmv_csr_dev **out) {
     return guarded("csr_upload", [&] { return csr_upload_impl<double>(M, N, row_ptr, col_idx, values, row0, row1, out); });
@@ -940,6 +1000,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
     if (m->M_local == 0) return 0;
     T *y = y_full + m->row0;
     if (variant == SPMV_CSR_AUTO) variant = m->auto_variant;
+    if (m->tiles_only && variant != SPMV_CSR_STREAM) return fail("csr_launch: a tiles-only handle runs the tile kernel only");
     switch (variant) {
         case SPMV_CSR_THREAD_ROW: {
             const int grid = (m->M_local + kBlock - 1) / kBlock;
@@ -964,7 +1025,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
             }
             break;
         case SPMV_CSR_STREAM: {
-            if (m->num_blocks > 0) {
+            if (m->num_blocks > 0 || m->tiles_only) {
                 const int per_xcd = (m->num_blocks + 7) / 8;
 #define SPMV_ARGS m->desc, m->row_ptr, m->col, (const T *)m->val, x, y
 #define SPMV_LAUNCH_PROD(NT, CAP, BLOCK)                                                          \
@@ -983,7 +1044,9 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                 // the x-window kernel reads whole aligned lines of x
                 const bool local = (g_stream_kind == -1 || g_stream_kind == 5) && m->local_blocks > 0 &&
                                    ((uintptr_t)x & (kLineBytes - 1)) == 0;
-                const bool tiled = !local && (g_stream_kind == -1 || g_stream_kind == 6) && m->tile_blocks > 0;
+                const bool tiled = !local && m->tile_blocks > 0 &&
+                                   (g_stream_kind == -1 || g_stream_kind == 6 || m->tiles_only);
+                if (m->tiles_only && !tiled) return fail("csr_launch: a tiles-only handle has nothing else to run");
                 if (tiled) {
                     // staging copies 16-byte pieces of x
                     const int stage_ok = ((uintptr_t)x & 15) == 0;

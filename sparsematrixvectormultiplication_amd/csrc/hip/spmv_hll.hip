@@ -162,7 +162,7 @@ int hll_fill_row_segments(spmv_hll_dev *m) {
 
 int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<long long> &off,
                       const std::vector<int> &mz, long long true_slots, bool upload_maxnz, const int *ja_host,
-                      int matrix_rows = -1, int row0 = 0) {
+                      int matrix_rows = -1, int row0 = 0, const double *as_host = nullptr) {
     m->M_total = matrix_rows < 0 ? total_rows : matrix_rows;
     m->row0 = row0;
     const int H = (int)mz.size();
@@ -210,6 +210,19 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
         }
     }
     if (!rc && m->local_blocks > 0) rc = hll_fill_row_segments(m);
+    // no x-window plan (columns too scattered): the 2-D tiles over the slab's rows, padding slots included -- the
+    // rows of hack h are maxnz[h] slots each, starting at hack_off[h] + i * maxnz[h] (needs the slab on the host)
+    if (!rc && m->local_blocks == 0 && ja_host && as_host && true_slots > 0 && off[H] < 0x7fffffffLL) {
+        std::vector<int> row_begin((size_t)total_rows), row_len((size_t)total_rows);
+        for (int r = 0; r < total_rows; ++r) {
+            const int h = r / kHack;
+            row_len[(size_t)r] = mz[(size_t)h];
+            row_begin[(size_t)r] = (int)(off[(size_t)h] + (long long)(r % kHack) * mz[(size_t)h]);
+        }
+        rc = csr_tiles_from_rows_f64(total_rows, m->M_total, row0, N, row_begin.data(), row_len.data(), true_slots, ja_host,
+                                     as_host, &m->tiles);
+        if (!rc && m->tiles) m->device_bytes += m->tiles->device_bytes;
+    }
     const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
     m->lanes_per_row = std::min(32, std::max(2, pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)))));
     return rc;
@@ -435,7 +448,8 @@ static int spmv_hip_hll_upload_part_body(const HLLMatrix *hll, int total_rows, i
         planned = hll_plan_on_device(m, rows, off, mz);
         if (planned < 0) rc = -1;
     }
-    if (!rc) rc |= hll_finish_handle(m, rows, N, off, mz, true_slots, true, planned ? nullptr : ja.data(), total_rows, row0);
+    if (!rc) rc |= hll_finish_handle(m, rows, N, off, mz, true_slots, true, planned ? nullptr : ja.data(), total_rows, row0,
+                                     as.data());
     if (!rc && planned)
         m->device_bytes += (size_t)m->local_blocks * 32 + ((size_t)m->local_lines + kLocalLinesMax) * 4 +
                            ((size_t)S + kPad) * 2;
@@ -509,13 +523,20 @@ static int spmv_hip_hll_from_csr_body(const spmv_csr_dev *csr, spmv_hll_dev **ou
             if (planned < 0) { rc = -1; break; }
         }
         std::vector<int> ja_host;
+        std::vector<double> as_host;
         if (g_stream_local && S > 0 && !planned) {
             ja_host.resize((size_t)S);
             e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
+            // (the values too: a slab without an x-window plan may get the tile plan, built on the host)
+            if (g_stream_tile != 0 && (g_stream_tile == 1 || (long long)M >= 512LL * 2048)) {
+                as_host.resize((size_t)S);
+                e = hipMemcpy(as_host.data(), m->AS, (size_t)S * sizeof(double), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) { rc = fail("hll_from_csr: AS download failed: %s", hipGetErrorString(e)); break; }
+            }
         }
         rc = hll_finish_handle(m, M, N, off, mz, true_slots, false, ja_host.empty() ? nullptr : ja_host.data(),
-                               csr->M_total, csr->row0);
+                               csr->M_total, csr->row0, as_host.empty() ? nullptr : as_host.data());
         if (!rc && planned)
             m->device_bytes += (size_t)m->local_blocks * 32 + ((size_t)m->local_lines + kLocalLinesMax) * 4 +
                                ((size_t)S + kPad) * 2;
@@ -560,6 +581,7 @@ extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
     (void)hipFree(m->lines);
     (void)hipFree(m->lja);
     (void)hipFree(m->row_seg);
+    spmv_hip_csr_free(m->tiles);
     (void)hipFree(m->x);
     (void)hipFree(m->y);
     delete m;
@@ -582,7 +604,20 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     out->algo_bytes = m->slots * 12 + 12LL * m->hacks + 8LL * ((long long)m->M + m->N);
     out->device_bytes = (long long)m->device_bytes;
     out->local_blocks = m->local_blocks;
-    out->stream_kernel = m->local_blocks > 0 ? 1 : 0;
+    out->stream_kernel = m->local_blocks > 0 ? 1 : m->tiles ? 2 : 0;
+    if (m->tiles) {
+        spmv_dev_info t;
+        if (spmv_hip_csr_info(m->tiles, &t) == 0) {
+            out->tile_blocks = t.tile_blocks;
+            out->tile_passes = t.tile_passes;
+            out->tile_entries = t.tile_entries;
+            out->tile_staged_entries = t.tile_staged_entries;
+            out->tile_long_rows = t.tile_long_rows;
+            out->tile_long_items = t.tile_long_items;
+            out->tile_long_entries = t.tile_long_entries;
+            out->stream_bytes = t.stream_bytes + 12LL * m->hacks;
+        }
+    }
     out->local_stage_lines = m->local_stage_lines;
     out->local_lines = m->local_lines;
     if (m->local_blocks > 0)
@@ -656,6 +691,8 @@ int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_fu
                                        m->lja, m->AS, x, y);
                 break;
             }
+            if (m->tiles && (g_stream_kind == -1 || g_stream_kind == 6))  // csr_tile over the slab's rows
+                return csr_launch_any(m->tiles, SPMV_CSR_STREAM, x, y_full, s);
             const size_t lds = 32 + ((size_t)m->stage_slots + 2) * sizeof(double);
 #define SPMV_HLL_LDS_LAUNCH(MAXU)                                                                  \
     hipLaunchKernelGGL((hll_lds<double, true, MAXU>), dim3(m->num_blocks), dim3(kBlock), lds, s,    \

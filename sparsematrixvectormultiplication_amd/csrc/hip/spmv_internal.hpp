@@ -139,6 +139,7 @@ struct spmv_csr_dev {
     int *interior_ids = nullptr, *boundary_ids = nullptr;
     int num_interior = 0, num_boundary = 0;
     bool have_split = false;
+    bool tiles_only = false;  // a handle made of tile plans alone (the tile side of an HLL handle): STREAM only
     // csr_tile (2-D tiles: row-block accumulators in LDS x column passes), for matrices without an x-window plan
     int tile_blocks = 0;              // 0: no tiles
     int tile_rows = 0;                // rows per block
@@ -192,6 +193,7 @@ struct spmv_hll_dev {
     int *lines = nullptr;
     unsigned short *lja = nullptr;
     unsigned *row_seg = nullptr;   // [M] a row's (first slot in its window | slots << 16)
+    spmv_csr_dev *tiles = nullptr; // csr_tile over the slab's rows (padding slots included), when the slab gets no x-window plan
     int local_blocks = 0, local_stage_lines = 0;
     long long local_lines = 0;
     double *x = nullptr;
@@ -220,6 +222,10 @@ struct LocalPlan {
 // spmv_csr.hip: a handle around device arrays that already hold the matrix (ownership passes to the handle
 // on success only); col / val carry kPad zeroed entries behind the last one
 int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_val, spmv_csr_dev **out);
+// spmv_csr.hip: tile plans alone for rows given as (first entry, length) over host arrays (an HLL slab's rows);
+// *out = NULL when the rows get no plan
+int csr_tiles_from_rows_f64(int M_local, int M_total, int row0, int N, const int *row_begin, const int *row_len,
+                            long long entries, const int *col, const double *val, spmv_csr_dev **out);
 
 // launchers the timing / exchange code calls across translation units
 int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s);

@@ -16,7 +16,7 @@ from .host import CsrHost, HllHost
 CSR_AUTO, CSR_THREAD_ROW, CSR_WAVE_ROW, CSR_SUBWAVE, CSR_STREAM = 0, 1, 2, 3, 4
 HLL_AUTO, HLL_THREAD_ROW, HLL_SUBWAVE, HLL_LDS = 0, 1, 2, 3
 CSR_STREAM_KERNELS = ("csr_stream", "csr_stream_local", "csr_stream_short", "csr_tile")
-HLL_LDS_KERNELS = ("hll_lds", "hll_lds_local")
+HLL_LDS_KERNELS = ("hll_lds", "hll_lds_local", "csr_tile (HLL slab rows)")
 CSR_VARIANTS = {"thread_row": CSR_THREAD_ROW, "wave_row": CSR_WAVE_ROW, "subwave": CSR_SUBWAVE,
                 "stream": CSR_STREAM}
 HLL_VARIANTS = {"thread_row": HLL_THREAD_ROW, "subwave": HLL_SUBWAVE, "lds": HLL_LDS}

@@ -40,7 +40,7 @@ def test_c_driver_runs_reference_protocol_on_golden_matrices(tmp_path, gpu):
     assert all(int(d["block_size_csr_warp"]) % 64 == 0 for d in dims)
     shapes = list(csv.DictReader(open(out / "spmv_results_hip_launch_shape.csv")))
     assert len(shapes) == len(rows)
-    assert all(sh["csr_stream_kernel"] in ("csr_stream", "csr_stream_local", "csr_stream_short") for sh in shapes)
+    assert all(sh["csr_stream_kernel"] in ("csr_stream", "csr_stream_local", "csr_stream_short", "csr_tile") for sh in shapes)
     # running again appends, never wipes (the reference deletes the result directory)
     subprocess.run([DRIVER, "--out", str(out), "--iters", "6", os.path.join(GOLDEN, "general_matrix.mtx")],
                    check=True, capture_output=True, timeout=120)

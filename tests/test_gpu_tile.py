@@ -175,3 +175,47 @@ def test_tile_kernel_on_reference_golden(gpu, name):
             for x, key in ((np.ones(csr.N), "y_ones"), (g["x_rand"], "y_rand")):
                 assert_parity(dev.spmv(x, sp.CSR_STREAM), g[key], csr.row_ptr, csr.col_idx, csr.values, x,
                               what=f"{name}/{key}/tile")
+
+
+@pytest.mark.parametrize("mean,sigma", [(16, None), (12, 6000)])
+def test_hll_slab_rows_through_the_tile_kernel(gpu, oracle, mean, sigma):
+    """An HLL slab whose columns are too scattered for the x-window plan gets the tile plan over its rows (padding
+    slots included): host-built slab and device-built slab, whole matrix and a hack range, against the oracle and
+    bit-reproducible; the gather kernel hll_lds on the same handle agrees within the gate."""
+    from _util import coo_from_csr
+    rng = np.random.default_rng(17 + mean)
+    M, N = 9001, (1_500_000 if sigma is None else 9001)
+    rp, col, val = scattered(rng, M, N, mean, sigma=sigma)
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_serial(rp, col, val, x)
+    r, c, v = coo_from_csr(rp, col, val)
+    hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, N, r, c, v))
+    with tuned(stream_tile=1, tile_rows=1024):
+        with sp.HllDevice(hll) as dev:
+            info = dev.info()
+            if info["local_blocks"]:
+                pytest.skip("narrow enough for the x-window plan")
+            assert info["stream_kernel"] == 2 and info["tile_entries"] + info["tile_long_entries"] == info["slots"]
+            first = None
+            for rep in range(3):
+                sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * 8)
+                y = dev.spmv(x, sp.HLL_LDS)
+                assert_parity(y, y_ref, rp, col, val, x, what=f"hll tiles rep={rep}")
+                first = y if first is None else first
+                assert y.tobytes() == first.tobytes()
+            with tuned(stream_kind=0):
+                assert_parity(dev.spmv(x, sp.HLL_LDS), y_ref, rp, col, val, x, what="hll_lds on the same handle")
+            for vname, variant in sorted(sp.HLL_VARIANTS.items()):
+                assert_parity(dev.spmv(x, variant), y_ref, rp, col, val, x, what=f"hll {vname}")
+        # a hack range keeps global rows; the slab built on the device gets the plan as well
+        hb = sp.partition_hacks(hll, 3)
+        rb = sp.hack_bounds_to_rows(hb, M)
+        with sp.HllDevice(hll, int(hb[1]), int(hb[2])) as part:
+            assert part.info()["stream_kernel"] == 2
+            y = part.spmv(x, sp.HLL_LDS)
+            lo, hi = int(rb[1]), int(rb[2])
+            assert_parity(y[lo:hi], y_ref[lo:hi], rp[lo:hi + 1] - rp[lo], col[rp[lo]:rp[hi]], val[rp[lo]:rp[hi]], x,
+                          what="hll tiles, hack range")
+        with sp.CsrDevice(M, N, rp, col, val) as cdev, sp.HllDevice.from_csr_device(cdev) as built:
+            assert built.info()["stream_kernel"] == 2
+            assert_parity(built.spmv(x, sp.HLL_AUTO), y_ref, rp, col, val, x, what="hll tiles, device-built slab")

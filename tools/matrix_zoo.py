@@ -93,5 +93,5 @@ for name, make in zoo:
     gb = info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9
     hgb = hi_info["algo_bytes"] / (hms.mean() * 1e-3) / 1e9
     print(f"| {name} | {M} | {info['nz']} | {sp.device.CSR_STREAM_KERNELS[info['stream_kernel']]} | "
-          f"{ms.mean() * 1e3:.1f} | {gb:.0f} | {gb / 80:.1f} | {'hll_lds_local' if hi_info['local_blocks'] else 'hll_lds'} | "
+          f"{ms.mean() * 1e3:.1f} | {gb:.0f} | {gb / 80:.1f} | {sp.device.HLL_LDS_KERNELS[hi_info['stream_kernel']]} | "
           f"{hms.mean() * 1e3:.1f} | {hgb / 80:.1f} | ok |", flush=True)
