@@ -182,10 +182,24 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     build_striped_pieces(Ml, rp, hcol, leftover, stripe_cols, tb.tile_pieces, tb.tile_long);
 }
 
+// csr_tile asks for up to a CU's whole LDS as dynamic shared memory; HIP wants that allowed per kernel beyond
+// 64 KiB.  Done once per value type, at upload (not at launch: a launch may sit inside a graph capture).
+template <typename T>
+int tile_allow_lds() {
+    static bool done = false;
+    if (done) return 0;
+    const void *fns[4] = {(const void *)csr_tile<T, false, 2048, kTileTrips>, (const void *)csr_tile<T, true, 2048, kTileTrips>,
+                          (const void *)csr_tile<T, false, 4096, kTileTrips>, (const void *)csr_tile<T, true, 4096, kTileTrips>};
+    for (const void *fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+    return 0;
+}
+
 // the plans' arrays -> the handle
 template <typename T>
 int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
     int rc = 0;
+    if ((tb.have_tiles || tb.have_long_tiles) && tile_allow_lds<T>()) return -1;
     if (tb.have_tiles) {
         const TilePlan<T> &tiles = tb.tiles;
         rc |= upload_array(&m->tile_block_pass, tiles.block_pass.data(), tiles.block_pass.size(), 1);
@@ -735,10 +749,12 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
         for (int p = plan.block_pass[b]; p < plan.block_pass[b + 1]; ++p) {
             const int4 d = plan.pass_desc[p];
             const int count = d.y, wbase = d.z, wlen = d.w;
-            if (count <= 0 || count > chunk || (d.x & 3) || (wbase & 3) || (wlen & 3) || wlen < 0)
+            constexpr int kPer = 16 / (int)sizeof(T);
+            if (count <= 0 || count > chunk || (d.x & 3) || (wbase & 3) || (wlen % kPer) || wlen < 0)
                 return fail("tile_plan_check: pass %d is malformed", p);
             if ((size_t)d.x + (size_t)count > plan.tcol.size() - kTileChunkMax) return fail("tile_plan_check: pass %d leaves the arrays", p);
-            if (wlen && (wlen > win_cols || wbase + wlen > N + 3)) return fail("tile_plan_check: window of pass %d is too wide", p);
+            if (wlen && (wlen > win_cols || wbase + wlen > (N + kPer - 1) / kPer * kPer))
+                return fail("tile_plan_check: window of pass %d is too wide or leaves x", p);
             int prev_row = -1;
             long long cmin = 1LL << 40, cmax = -1;
             for (int i = 0; i < count; ++i) {
@@ -1055,13 +1071,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                                                     (stage_ok ? (size_t)m->tile_max_win * sizeof(T) : 0));
                     const bool tnt = m->nz * (long long)(sizeof(T) + 6) > (128LL << 20);
                     const int which = (m->tile_chunk == 4096 ? 2 : 0) + (tnt ? 1 : 0);
-                    static size_t lds_allowed[4] = {0, 0, 0, 0};  // per instantiation
-                    const void *fns[4] = {(const void *)csr_tile<T, false, 2048, kTileTrips>, (const void *)csr_tile<T, true, 2048, kTileTrips>,
-                                          (const void *)csr_tile<T, false, 4096, kTileTrips>, (const void *)csr_tile<T, true, 4096, kTileTrips>};
-                    if (lds > lds_allowed[which]) {
-                        HIP_TRY(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        lds_allowed[which] = lds;
-                    }
+                    // (more than 64 KiB of dynamic LDS: allowed for these kernels once, at upload -- tile_allow_lds)
 #define SPMV_TILE(NT, CH, TRIPS)                                                                                       \
     hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s,      \
                        m->tile_blocks, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,        \
@@ -1076,10 +1086,6 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                         const auto &L = m->lt;
                         const size_t llds = (size_t)kTileSlotBytes + (size_t)L.rows_per_block * sizeof(T) +
                                             (stage_ok ? (size_t)L.max_win * sizeof(T) : 0);
-                        if (llds > lds_allowed[which]) {
-                            HIP_TRY(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
-                            lds_allowed[which] = llds;
-                        }
 #define SPMV_LTILE(NT, CH, TRIPS)                                                                                      \
     hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((L.items + 7) / 8 * 8), dim3(kTileBlock), llds, s, L.items,   \
                        L.rows_per_block, stage_ok, g_tile_probe, (const int4 *)L.work, (T *)L.slab, L.block_row,        \

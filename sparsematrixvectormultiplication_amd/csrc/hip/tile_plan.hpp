@@ -140,8 +140,12 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
                 std::sort(pass.begin(), pass.end(),
                           [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
             const int count = (int)pass.size();
+            // the staged slice: whole 16-byte pieces from a 16-byte aligned start, never past the piece that holds
+            // x[N - 1] (a caller's x need not have anything allocated behind it)
+            constexpr int kPer = 16 / (int)sizeof(T);
             const int wbase = cmin & ~3;
             int wlen = ((cmax - wbase + 1) + 3) & ~3;
+            wlen = std::min(wlen, ((int)col_top - wbase + kPer - 1) / kPer * kPer);
             const bool staged = wlen <= win_cols && (long long)count * density >= wlen;
             const int e_first = (int)out.tcol.size();
             int prev_row = -1;

@@ -219,3 +219,27 @@ def test_hll_slab_rows_through_the_tile_kernel(gpu, oracle, mean, sigma):
         with sp.CsrDevice(M, N, rp, col, val) as cdev, sp.HllDevice.from_csr_device(cdev) as built:
             assert built.info()["stream_kernel"] == 2
             assert_parity(built.spmv(x, sp.HLL_AUTO), y_ref, rp, col, val, x, what="hll tiles, device-built slab")
+
+
+def test_tile_kernel_inside_a_graph_replay_and_power_iteration(gpu, oracle):
+    """The tile kernel captured into a hipGraph (spmv_hip_csr_time_graph) and inside the on-device power iteration:
+    launches must not need anything that a capture forbids; the result stays the oracle's."""
+    rng = np.random.default_rng(41)
+    M = N = 20_000
+    rp, col, val = scattered(rng, M, N, 10, sigma=3000)
+    x = rng.uniform(0.5, 1.0, N)
+    y_ref = oracle.csr_serial(rp, col, val, x)
+    with tuned(stream_tile=1, tile_rows=1024):
+        with sp.CsrDevice(M, N, rp, col, val) as dev:
+            assert dev.info()["stream_kernel"] == 3
+            dev.set_x(x)
+            assert dev.time_graph(sp.CSR_STREAM, 5, 3) > 0
+            assert_parity(dev.get_y(), y_ref, rp, col, val, x, what="tile kernel replayed from a graph")
+            dev.set_x(x)
+            lam, _ = dev.power_iterate(3, use_graph=True)
+            xs = x.copy()
+            for _ in range(3):
+                ys = oracle.csr_serial(rp, col, val, xs)
+                lam_ref = float(np.linalg.norm(ys))
+                xs = ys / lam_ref
+            assert abs(lam - lam_ref) <= 1e-10 * lam_ref
