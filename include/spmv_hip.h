@@ -123,10 +123,11 @@ int spmv_hip_flush_cache(size_t bytes);
  *     "local_cap"     0 (auto = 2048) | 1024 | 2048 | 3072   stage of the x-window kernels (3072: +0.5..3 % on the
  *                     nlpkkt-like matrix depending on the box, -8 % on the cant-like one)
  *     "stream_tile"   -1 (auto) | 0 | 1   build the 2-D tile plan (csr_tile) when the matrix gets no x-window plan;
- *                     "tile_rows" 0 (auto = 2048) | 256..16384 rows per block, "tile_lmax" (1024) longest row kept in
- *                     the tiles, "tile_density" (16) columns per entry up to which a pass is staged in LDS, "tile_chunk" 0 (auto)
- *                     | 2048 | 4096 entries per pass, "tile_balance" 1 | 0 row blocks of equal entry / row counts, "tile_long" 1 | 0 a tile plan of
- *                     their own for the rows beyond tile_lmax (else: split-row kernels)
+ *                     "tile_rows" 0 (auto: 32 KiB of accumulators for banded matrices, up to 16384 rows for scattered
+ *                     ones) | a multiple of 256 in 256..16384 rows per block; "tile_lmax" (1024) longest row kept in
+ *                     the ordinary tiles; "tile_density" (16) columns per entry up to which a pass is staged in LDS;
+ *                     "tile_balance" 1 | 0 row blocks of equal entry / row counts; "tile_long" 1 | 0 | 2 a tile plan of
+ *                     their own for the rows beyond tile_lmax (0: split-row kernels, 2: however few they are)
  *   read at launch
  *     "stream_kind"   -1 (auto: x-window kernel when the handle has a plan, csr_tile when it has tiles, else
  *                     csr_stream) | 5 x-window | 6 csr_tile |
@@ -161,8 +162,8 @@ int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx
  * rows, rows handed to the split-row kernels because they alone touch too many lines. */
 int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, int *stats);
 /* The same for the csr_tile plan (row blocks x column passes, see spmv_dev_info.tile_*): builds it as upload
- * would with the given parameters (rows per block: power of two in 256..16384; lmax: longest row kept in the
- * tiles; density: columns per entry up to which a pass is staged; chunk: 2048 | 4096 entries per pass; balance: 1 = row blocks of about equal entry counts) and replays the kernel's bookkeeping with
+ * would with the given parameters (rows per block: multiple of 256 in 256..16384; lmax: longest row kept in the
+ * tiles; density: columns per entry up to which a pass is staged; chunk: 2048 entries per pass; balance: 1 = row blocks of about equal entry counts) and replays the kernel's bookkeeping with
  * integer checksums; needs no device.  stats[6] (optional): row blocks, passes, entries in tiles, entries in
  * staged passes, rows left to the split-row kernels, widest staged window (columns). */
 int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,

@@ -139,7 +139,7 @@ struct TileBuild {
 template <typename T>
 void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, const int *rp, long long nz, const int *hcol,
                    const T *hval, TileBuild<T> &tb) {
-    const int chunk = g_tile_chunk ? g_tile_chunk : 2048;
+    const int chunk = 2048;
     int rb = g_tile_rows;
     const int density = g_tile_density;
     if (!rb) {
@@ -188,8 +188,7 @@ template <typename T>
 int tile_allow_lds() {
     static bool done = false;
     if (done) return 0;
-    const void *fns[4] = {(const void *)csr_tile<T, false, 2048, kTileTrips>, (const void *)csr_tile<T, true, 2048, kTileTrips>,
-                          (const void *)csr_tile<T, false, 4096, kTileTrips>, (const void *)csr_tile<T, true, 4096, kTileTrips>};
+    const void *fns[2] = {(const void *)csr_tile<T, false, 2048, kTileTrips>, (const void *)csr_tile<T, true, 2048, kTileTrips>};
     for (const void *fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
     return 0;
@@ -833,8 +832,8 @@ extern "C" int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, co
                                             int rows_per_block, int lmax, int density, int chunk, int balance,
                                             long long *stats) {
     if (M < 0 || N < 0 || !row_ptr || (value_bytes != 4 && value_bytes != 8)) return fail("tile_plan_check: bad arguments");
-    if (rows_per_block < 256 || rows_per_block > kTileRowsMax || (rows_per_block & (rows_per_block - 1)) || lmax < 1 ||
-        lmax > 65536 || density < 1 || (chunk != 2048 && chunk != 4096))
+    if (rows_per_block < 256 || rows_per_block > kTileRowsMax || (rows_per_block & 255) || lmax < 1 ||
+        lmax > 65536 || density < 1 || chunk != 2048)
         return fail("tile_plan_check: bad plan parameters");
     const long long nz = row_ptr[M];
     if (nz > 0 && !col_idx) return fail("tile_plan_check: col_idx is NULL");
@@ -1070,16 +1069,14 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                                                 (size_t)kTileSlotBytes + (size_t)m->tile_rows * sizeof(T) +
                                                     (stage_ok ? (size_t)m->tile_max_win * sizeof(T) : 0));
                     const bool tnt = m->nz * (long long)(sizeof(T) + 6) > (128LL << 20);
-                    const int which = (m->tile_chunk == 4096 ? 2 : 0) + (tnt ? 1 : 0);
+                    const int which = tnt ? 1 : 0;
                     // (more than 64 KiB of dynamic LDS: allowed for these kernels once, at upload -- tile_allow_lds)
 #define SPMV_TILE(NT, CH, TRIPS)                                                                                       \
     hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s,      \
                        m->tile_blocks, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,        \
                        m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval, x, y)
                     if (which == 0) SPMV_TILE(false, 2048, kTileTrips);
-                    else if (which == 1) SPMV_TILE(true, 2048, kTileTrips);
-                    else if (which == 2) SPMV_TILE(false, 4096, kTileTrips);
-                    else SPMV_TILE(true, 4096, kTileTrips);
+                    else SPMV_TILE(true, 2048, kTileTrips);
 #undef SPMV_TILE
                     if (m->lt.items > 0) {
                         // the long rows' own tiles: work items -> slabs -> y (after the ordinary tiles wrote 0 there)
@@ -1091,9 +1088,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                        L.rows_per_block, stage_ok, g_tile_probe, (const int4 *)L.work, (T *)L.slab, L.block_row,        \
                        L.block_pass, L.pass, L.tcol, L.tkey, (const T *)L.tval, x, y)
                         if (which == 0) SPMV_LTILE(false, 2048, kTileTrips);
-                        else if (which == 1) SPMV_LTILE(true, 2048, kTileTrips);
-                        else if (which == 2) SPMV_LTILE(false, 4096, kTileTrips);
-                        else SPMV_LTILE(true, 4096, kTileTrips);
+                        else SPMV_LTILE(true, 2048, kTileTrips);
 #undef SPMV_LTILE
                         hipLaunchKernelGGL((tile_slab_finish<T>), dim3((L.rows + kFinishRows - 1) / kFinishRows),
                                            dim3(kFinishRows * kFinishGroups), 0, s, L.rows,

@@ -44,7 +44,6 @@ int g_stream_tile = -1;
 int g_tile_rows = 0;
 int g_tile_lmax = 1024;
 int g_tile_density = 16;
-int g_tile_chunk = 0;
 int g_tile_probe = 0;
 int g_tile_long = 1;
 int g_halo_overlap = 1;
@@ -164,16 +163,13 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "stream_tile")) {
         if (value < -1 || value > 1) return fail("set_tuning: stream_tile must be -1 (auto), 0 or 1");
         g_stream_tile = value;
-    } else if (!strcmp(key, "tile_rows")) {
-        if (value != 0 && (value < 256 || value > kTileRowsMax || (value & (value - 1))))
-            return fail("set_tuning: tile_rows must be 0 (auto) or a power of two in 256..%d", kTileRowsMax);
-        g_tile_rows = value;
     } else if (!strcmp(key, "tile_lmax")) {
         if (value < 1 || value > 65536) return fail("set_tuning: tile_lmax must be 1..65536");
         g_tile_lmax = value;
-    } else if (!strcmp(key, "tile_chunk")) {
-        if (value != 0 && value != 2048 && value != 4096) return fail("set_tuning: tile_chunk must be 0 (auto), 2048 or 4096");
-        g_tile_chunk = value;
+    } else if (!strcmp(key, "tile_rows")) {
+        if (value != 0 && (value < 256 || value > kTileRowsMax || (value & 255)))
+            return fail("set_tuning: tile_rows must be 0 (auto) or a multiple of 256 in 256..%d", kTileRowsMax);
+        g_tile_rows = value;
     } else if (!strcmp(key, "halo_overlap")) {
         g_halo_overlap = value != 0;
     } else if (!strcmp(key, "tile_long")) {
@@ -182,7 +178,7 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "tile_balance")) {
         g_tile_balance = value != 0;
     } else if (!strcmp(key, "tile_probe")) {
-        g_tile_probe = value & 7;
+        g_tile_probe = value & 31;
     } else if (!strcmp(key, "tile_density")) {
         if (value < 0 || value > 4096) return fail("set_tuning: tile_density must be 0 (never stage) .. 4096");
         g_tile_density = value;

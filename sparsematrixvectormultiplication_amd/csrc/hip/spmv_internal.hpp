@@ -48,7 +48,6 @@ extern int g_pipe_wgs_per_cu; // resident workgroups per CU the persistent grids
 extern int g_stream_tile;     // csr_tile plan at upload: -1 = auto (no x-window plan, enough rows), 0 = never, 1 = whenever no x-window plan
 extern int g_tile_rows;       // rows per block: 0 = auto, else a power of two in 256..8192
 extern int g_tile_lmax;       // rows longer than this stay with the split-row kernels
-extern int g_tile_chunk;      // entries per pass: 0 = auto, 2048 (two workgroups per CU) or 4096 (one)
 extern int g_tile_probe;      // measurement only: bit 0 no LDS staging, bit 1 no gathers, bit 2 no run sums (y is then wrong)
 extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keeps the workgroups in step), 0: equal row counts
 extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile plan of their own (compacted rows, work items, slabs)
@@ -143,7 +142,7 @@ struct spmv_csr_dev {
     // csr_tile (2-D tiles: row-block accumulators in LDS x column passes), for matrices without an x-window plan
     int tile_blocks = 0;              // 0: no tiles
     int tile_rows = 0;                // rows per block
-    int tile_chunk = 0;               // entries per pass at most (2048 | 4096)
+    int tile_chunk = 0;               // entries per pass at most (2048)
     int tile_lds_min = 0;             // LDS bytes to ask for at least (scattered matrices: one workgroup per CU)
     int tile_passes = 0;
     int tile_max_win = 0;             // widest staged window (columns)

@@ -49,6 +49,8 @@ constexpr int kTileRowMask = 0x3fff;
 constexpr int kTileTripBytes = kTileBlock * 16;  // x bytes one staging trip of the workgroup copies
 constexpr int kTileTrips = 5;        // trips per pass: windows of up to 40 KiB
 constexpr int kTileAhead = 3;        // passes whose entries are in flight beyond the one being worked on
+// (a compact variant -- 24 KiB windows, 1 pass ahead, 79 VGPRs, three workgroups per CU -- was measured and is no
+// faster: road-like 191 us at 3072 rows against 173 us for this one at 4096, profiles/r2_ab_csr_tile.txt)
 constexpr int kTileSlotBytes = 256;  // LDS in front of the accumulators: one (sum, closed) slot per wavefront and quad
 
 template <typename T> struct vec4v;  // four values of a lane's quad
@@ -107,6 +109,55 @@ __device__ __forceinline__ T lane_down(T v, int delta) {  // value of lane + del
     return __shfl_down(v, delta, 64);
 }
 
+// value of lane + N inside the lane's row of 16 (DPP row_shl: a VALU move, no LDS crossbar); 0 past the row's end
+template <int CTRL>
+__device__ __forceinline__ double row_down(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ float row_down(float v) {
+    return __int_as_float(dpp_i32<CTRL>(__float_as_int(v)));
+}
+__device__ __forceinline__ double read_lane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float read_lane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// Right-to-left segmented scan over the 64 lanes: on entry r = the lane's leading partial sum, h = 1 when the lane
+// holds a head; on exit r(s) = lead(s) + lead(s + 1) + ... up to and including the first lane >= s that holds a head
+// (or the wavefront's end), h(s) = whether there was one.  Rows of 16 lanes by DPP row shifts, the four rows stitched
+// from the last to the first with v_readlane: ~100 cycles of dependent VALU / SALU work where six ds_bpermute steps
+// (three crossbar trips each) were ~600.
+template <typename T>
+__device__ __forceinline__ void chain_scan(T &r, int &h, int lane) {
+    const int lir = lane & 15;
+#define SPMV_CHAIN_STEP(N, CTRL)              \
+    {                                         \
+        const T rn = row_down<CTRL>(r);       \
+        const int hn = dpp_i32<CTRL>(h);      \
+        if (lir + N < 16 && !h) {             \
+            r += rn;                          \
+            h = hn;                           \
+        }                                     \
+    }
+    SPMV_CHAIN_STEP(1, 0x101)  // row_shl:1
+    SPMV_CHAIN_STEP(2, 0x102)
+    SPMV_CHAIN_STEP(4, 0x104)
+    SPMV_CHAIN_STEP(8, 0x108)
+#undef SPMV_CHAIN_STEP
+#pragma unroll
+    for (int q = 2; q >= 0; --q) {  // what a chain that leaves row q collects from row q + 1 on
+        const T rn = read_lane(r, 16 * (q + 1));
+        const int hn = __builtin_amdgcn_readlane(h, 16 * (q + 1));
+        if ((lane >> 4) == q && !h) {
+            r += rn;
+            h = hn;
+        }
+    }
+}
+
 // One pass.  (cc, ck, cv) and cw hold its entries and its x slice; the loads this pass sends out, in this order
 // (vmcnt retires in order, so what is needed soonest goes first): its own gathers, the x slice of the NEXT pass
 // (nw; served by L2), the entries of the pass kTileAhead passes further on (fc, fk, fv; served by HBM, whose
@@ -144,9 +195,9 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
         }
     }
     // (the last passes re-issue the block's last one: the count in flight stays a constant)
-    tile_issue_window<T, TRIPS>(nw, pass_desc[min(p + 1, p_last)], stage_ok, x);
+    if (!(probe & 8)) tile_issue_window<T, TRIPS>(nw, pass_desc[min(p + 1, p_last)], stage_ok, x);  // (probe bit 3: no x slices)
     tile_issue_entries<T, NT, CH>(fc, fk, fv, pass_desc[min(p + kTileAhead, p_last)], tcol, tkey, tval);
-    __syncthreads();  // xs is in place; everybody is done with the previous pass's wave slots
+    if (!(probe & 16)) __syncthreads();  // xs is in place; everybody is done with the previous pass's wave slots
     // ---- a lane's quads: products, the runs that close inside the quad, the open ends
     T lead[kQuads], tail[kQuads];   // sum before the quad's first head (the whole quad without one) / from its last head on
     int tail_row[kQuads];           // local row of the run `tail` belongs to (-1: none)
@@ -191,15 +242,8 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
     for (int u = 0; u < kQuads; ++u) {
         T r = lead[u];
         int h = has_head[u] ? 1 : 0;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const T rn = lane_down(r, dlt);
-            const int hn = lane_down(h, dlt);
-            if (lane + dlt < 64 && !h) {
-                r += rn;
-                h = hn;
-            }
-        }
+        // short rows: every lane of the wavefront holds a head, every chain ends in the next lane -- no scan
+        if (__ballot(h != 0) != ~0ull) chain_scan(r, h, lane);  // wave-uniform
         if (lane == 0) {  // what the previous wavefront's open run collects from this one, and whether it ends here
             wave_r[u * kTileWaves + wave] = r;
             wave_h[u * kTileWaves + wave] = h;
@@ -233,9 +277,9 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
 // One workgroup per row block; passes software-pipelined: while pass p is multiplied and summed, the x slice of
 // pass p + 1 and the entries of passes p + 1 .. p + 3 are already on their way into registers.
 // pass = {first entry (multiple of 4), entries, first staged column (multiple of 4), staged columns (0: gather)}
-// (second launch bound = wavefronts per SIMD: chunk 2048 is sized for two resident workgroups per CU)
+// (second launch bound = wavefronts per SIMD: two resident workgroups per CU)
 template <typename T, bool NT, int CH, int TRIPS>
-__global__ __launch_bounds__(kTileBlock, CH == 2048 ? 4 : 2) void csr_tile(int num_blocks, int rows_per_block,
+__global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int rows_per_block,
                                                                           int stage_ok, int probe,
                                                                           const int4 *__restrict__ work, T *__restrict__ slab,
                                                                           const int *__restrict__ block_row,
@@ -282,17 +326,17 @@ __global__ __launch_bounds__(kTileBlock, CH == 2048 ? 4 : 2) void csr_tile(int n
         // entries: four rotating register sets (the current pass + kTileAhead = 3 in flight), x slices: two
         SPMV_TILE_ENTRY_REGS(e0);
         SPMV_TILE_ENTRY_REGS(e1);
-        SPMV_TILE_ENTRY_REGS(e2);
-        SPMV_TILE_ENTRY_REGS(e3);
         v4u wa[TRIPS], wb[TRIPS];
         const int pl = p1 - 1;
+#define SPMV_TILE_PASS(cur, fill, wcur, wnext, P)                                                                       \
+    tile_pass<T, NT, CH, TRIPS>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), wnext, P, pl, pass_desc,    \
+                                stage_ok, probe, acc, xs, wave_r, wave_h, tcol, tkey, tval, x)
+        SPMV_TILE_ENTRY_REGS(e2);
+        SPMV_TILE_ENTRY_REGS(e3);
         tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e0), pass_desc[p0], tcol, tkey, tval);
         tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e1), pass_desc[min(p0 + 1, pl)], tcol, tkey, tval);
         tile_issue_window<T, TRIPS>(wa, pass_desc[p0], stage_ok, x);
         tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e2), pass_desc[min(p0 + 2, pl)], tcol, tkey, tval);
-#define SPMV_TILE_PASS(cur, fill, wcur, wnext, P)                                                                       \
-    tile_pass<T, NT, CH, TRIPS>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), wnext, P, pl, pass_desc,    \
-                                stage_ok, probe, acc, xs, wave_r, wave_h, tcol, tkey, tval, x)
         for (int p = p0; p < p1; p += 4) {  // wave-uniform
             SPMV_TILE_PASS(e0, e3, wa, wb, p);
             if (p + 1 < p1) SPMV_TILE_PASS(e1, e0, wb, wa, p + 1);

@@ -37,7 +37,7 @@ class tuned:
 
     def __exit__(self, *exc):
         defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 16, "stream_kind": -1,
-                    "tile_balance": 1, "tile_chunk": 0, "tile_long": 1}
+                    "tile_balance": 1, "tile_long": 1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 

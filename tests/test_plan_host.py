@@ -131,7 +131,7 @@ def _scattered(rng, M, N, mean, sigma=None):
 
 
 @pytest.mark.parametrize("vb", [8, 4])
-@pytest.mark.parametrize("rows_per_block,chunk", [(256, 2048), (2048, 2048), (2048, 4096)])
+@pytest.mark.parametrize("rows_per_block,chunk", [(256, 2048), (2048, 2048), (3072, 2048)])
 def test_tile_plan_on_scattered_banded_and_skewed_matrices(vb, rows_per_block, chunk):
     import functools
     real = sp.csr_tile_plan_check

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The nlpkkt120-like matrix through csr_stream_local and hll_lds_local, a few launches each (to be run under
-rocprofv3: which counters differ between the two x-window kernels on the same matrix?)."""
+"""The nlpkkt120-like (kkt) or FEM-shaped (big) matrix through csr_stream_local and hll_lds_local in ONE process,
+alternating (timing order matters on a card whose clocks move), a few launches each.  Also the thing to run under
+rocprofv3 --pmc to see which counters differ between the two x-window kernels on the same matrix."""
 import os
 import sys
 
@@ -11,12 +12,15 @@ import sparsematrixvectormultiplication_amd as sp  # noqa: E402
 from sparsematrixvectormultiplication_amd import synth  # noqa: E402
 
 sp.hip_init(0)
-M, rp, col, val = synth.kkt_like() if (len(sys.argv) < 2 or sys.argv[1] == "kkt") else synth.fem_like((40, 40, 257), 1)
+which = sys.argv[1] if len(sys.argv) > 1 else "kkt"
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+M, rp, col, val = synth.kkt_like() if which == "kkt" else synth.fem_like((40, 40, 257), 1)
 with sp.CsrDevice(M, M, rp, col, val) as dev:
     dev.set_x(np.ones(M))
-    ms = dev.time(sp.CSR_STREAM, 2, 8, zero_y=False)
-    print(f"csr {ms.mean() * 1e3:.1f} us")
     with sp.HllDevice.from_csr_device(dev) as h:
         h.set_x(np.ones(M))
-        hms = h.time(sp.HLL_LDS, 2, 8, zero_y=False)
-        print(f"hll {hms.mean() * 1e3:.1f} us slots={h.info()['slots']} blocks={h.info()['local_blocks']}")
+        for r in range(rounds):
+            hms = h.time(sp.HLL_LDS, 2, 20, zero_y=False)
+            ms = dev.time(sp.CSR_STREAM, 2, 20, zero_y=False)
+            print(f"round {r}: hll {hms.mean() * 1e3:.1f} us (min {hms.min() * 1e3:.1f})   csr {ms.mean() * 1e3:.1f} us (min {ms.min() * 1e3:.1f})   "
+                  f"slots={h.info()['slots']} nnz={dev.info()['nz']}", flush=True)

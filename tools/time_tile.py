@@ -44,7 +44,7 @@ CASES = {
 want = sys.argv[1:] or list(CASES)
 tile_rows = [int(v) for v in os.environ.get("TILE_ROWS", "2048").split(",")]
 dens = [int(v) for v in os.environ.get("TILE_DENSITY", "16").split(",")]
-chunks = [int(v) for v in os.environ.get("TILE_CHUNK", "2048").split(",")]
+chunks = [2048]
 sp.hip_init(0)
 for name in want:
     t = time.perf_counter()
@@ -63,7 +63,6 @@ for name in want:
               flush=True)
     for tr, dn, ch in [(a, b, c) for c in chunks for a in tile_rows for b in dens]:
         if True:
-            set_tuning("tile_chunk", ch)
             set_tuning("tile_balance", int(os.environ.get("TILE_BALANCE", "1")))
             set_tuning("tile_long", int(os.environ.get("TILE_LONG", "1")))
             set_tuning("tile_lmax", int(os.environ.get("TILE_LMAX", "1024")))
@@ -82,7 +81,7 @@ for name in want:
                     pm = dev.time(sp.CSR_STREAM, 2, 10, zero_y=False)
                     print(f"      probe {probe} (1 no staging, 2 no gathers, 4 no run sums): {pm.mean() * 1e3:8.1f} us", flush=True)
                     set_tuning("tile_probe", 0)
-                print(f"   tile chunk={ch} rows={tr:5d} density={dn:3d}: {ms.mean() * 1e3:8.1f} us  {info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  "
+                print(f"   tile rows={tr:5d} density={dn:3d}: {ms.mean() * 1e3:8.1f} us  {info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  "
                       f"{info['algo_bytes'] / ms.mean() / 1e6 / 80:5.1f} %  blocks={info['tile_blocks']} passes={info['tile_passes']} "
                       f"staged={info['tile_staged_entries'] / max(1, info['tile_entries']):.2f} split_rows={info['tile_split_rows']} "
                       f"in_tiles={info['tile_entries'] / nnz:.2f} long_rows={info['tile_long_rows']} long_items={info['tile_long_items']} in_long={info['tile_long_entries'] / nnz:.2f} format_bytes={info['stream_bytes']} upload={up:.1f}s "
@@ -90,4 +89,3 @@ for name in want:
     set_tuning("stream_tile", -1)
     set_tuning("tile_rows", 0)
     set_tuning("tile_density", 16)
-    set_tuning("tile_chunk", 0)
