@@ -98,7 +98,7 @@ bool build_long_tiles(int M, int N, const int *rp, const int *row_len, const int
         vlen[v] = row_len[rows[v]];
     }
     if (!tile_build<T>((int)rows.size(), N, vbegin.data(), vlen.data(), col, val, kRowsPerBlock, (1 << kPosBits) - 1,
-                       g_tile_density, chunk, true, kPosBits, plan))
+                       g_tile_density, chunk, true, kPosBits, plan, g_tile_pack != 0))
         return false;
     for (int r : rows) split[(size_t)r] = 0;
     // work items: ~4096 of them over all blocks, at least 4 passes each
@@ -148,7 +148,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         const int sample = std::min(Ml, 8 * banded_rows), s0 = (Ml - sample) / 2;
         TilePlan<T> probe;
         const bool ok = tile_build<T>(sample, N, row_begin + s0, row_len + s0, hcol, hval, banded_rows, g_tile_lmax, density,
-                                      chunk, g_tile_balance != 0, 17, probe);
+                                      chunk, g_tile_balance != 0, 17, probe, g_tile_pack != 0);
         if (ok && probe.staged_entries * 2 >= probe.entries) {
             rb = banded_rows;
         } else {
@@ -158,7 +158,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
-                                  g_tile_balance != 0, 17, tb.tiles);
+                                  g_tile_balance != 0, 17, tb.tiles, g_tile_pack != 0);
     // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
     if (tb.have_tiles && g_stream_tile < 0 && !g_tile_long && tb.tiles.entries * 2 < nz) tb.have_tiles = false;
     if (!tb.have_tiles) return;
@@ -747,7 +747,9 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
         long long last_max_col = -1;
         for (int p = plan.block_pass[b]; p < plan.block_pass[b + 1]; ++p) {
             const int4 d = plan.pass_desc[p];
-            const int count = d.y, wbase = d.z, wlen = d.w;
+            const int count = d.y, wbase = d.z, wlen = d.w & (kTilePassPacked - 1);
+            const bool packed = (d.w & kTilePassPacked) != 0;
+            if (packed && !wlen) return fail("tile_plan_check: pass %d is packed without a window", p);
             constexpr int kPer = 16 / (int)sizeof(T);
             if (count <= 0 || count > chunk || (d.x & 3) || (wbase & 3) || (wlen % kPer) || wlen < 0)
                 return fail("tile_plan_check: pass %d is malformed", p);
@@ -757,8 +759,12 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
             int prev_row = -1;
             long long cmin = 1LL << 40, cmax = -1;
             for (int i = 0; i < count; ++i) {
-                const int c = plan.tcol[(size_t)d.x + i];
-                const unsigned key = plan.tkey[(size_t)d.x + i];
+                // a pass that can be staged holds packed words; decode as the kernel does
+                const unsigned word = (unsigned)plan.tcol[(size_t)d.x + i];
+                const int c = packed ? wbase + (int)(word & kTilePackColMask) : (int)word;
+                const unsigned key = packed ? ((word >> 16) & (unsigned)kTileHead) | ((word >> kTilePackShift) & (unsigned)kTileRowMask)
+                                            : plan.tkey[(size_t)d.x + i];
+                if (packed && key != plan.tkey[(size_t)d.x + i]) return fail("tile_plan_check: packed key of entry %d in pass %d is wrong", i, p);
                 const int lrow = (int)(key & kTileRowMask);
                 if ((unsigned)c >= (unsigned)N || lrow >= nrows) return fail("tile_plan_check: entry %d of pass %d is out of range", i, p);
                 if (wlen && (c < wbase || c >= wbase + wlen)) return fail("tile_plan_check: staged pass %d misses column %d", p, c);
@@ -973,7 +979,8 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
         out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
                             4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
     else if (m->tile_blocks > 0)  // tiles: 4-byte column + 2-byte key + value per (padded) entry; rows beyond the limit as CSR
-        out->stream_bytes = (m->tile_padded + m->lt.padded) * (vb + 6) + 16LL * (m->tile_passes + m->lt.passes) +
+        out->stream_bytes = (m->tile_padded + m->lt.padded) * (vb + 6) - (g_tile_pack ? 2 : 0) * (m->tile_staged + m->lt.staged) +
+                            16LL * (m->tile_passes + m->lt.passes) +
                             4LL * m->tile_blocks + 2 * vb * (long long)m->lt.items * m->lt.rows_per_block +
                             (m->nz - m->tile_entries - m->lt.entries) * (vb + 4) + 16LL * m->tile_num_pieces +
                             vb * m->M_local + vb * m->N;

@@ -45,6 +45,7 @@ int g_tile_rows = 0;
 int g_tile_lmax = 1024;
 int g_tile_density = 16;
 int g_tile_probe = 0;
+int g_tile_pack = 1;
 int g_tile_long = 1;
 int g_halo_overlap = 1;
 int g_tile_balance = 1;
@@ -172,6 +173,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_tile_rows = value;
     } else if (!strcmp(key, "halo_overlap")) {
         g_halo_overlap = value != 0;
+    } else if (!strcmp(key, "tile_pack")) {
+        g_tile_pack = value != 0;
     } else if (!strcmp(key, "tile_long")) {
         if (value < 0 || value > 2) return fail("set_tuning: tile_long must be 0, 1 (rows with >= 2^20 entries together) or 2 (always)");
         g_tile_long = value;

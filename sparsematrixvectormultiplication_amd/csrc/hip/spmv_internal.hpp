@@ -51,6 +51,7 @@ extern int g_tile_lmax;       // rows longer than this stay with the split-row k
 extern int g_tile_probe;      // measurement only: bit 0 no LDS staging, bit 1 no gathers, bit 2 no run sums (y is then wrong)
 extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keeps the workgroups in step), 0: equal row counts
 extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile plan of their own (compacted rows, work items, slabs)
+extern int g_tile_pack;       // 1: passes that can be staged store head | row | column offset in one 32-bit word (no key read)
 extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
 extern int g_num_cus;
 extern int g_probe_mask;      // csr_probe: table size - 1 (entries) of the folded gather

@@ -19,7 +19,8 @@
 //   * a pass whose column range is narrow and dense enough is STAGED: its slice of x is copied into
 //     LDS with full-width coalesced loads and the per-entry lookups become ds_reads (the x-window
 //     idea with a dense window instead of a line list);
-//   * inside a pass an entry carries a 16-bit key {head flag, local row} and every lane holds FOUR
+//   * inside a pass an entry carries a key {head flag, local row} -- 16 bits beside a 32-bit column, or, in a
+//     pass that can be staged, packed with the column's offset in the slice into one 32-bit word -- and every lane holds FOUR
 //     CONSECUTIVE entries, so most of a row's run is added up in registers: runs that begin and end
 //     inside a lane go straight to the accumulator; a run that crosses lanes is finished by a
 //     right-to-left segmented scan over the lanes' leading partial sums (ds_bpermute inside a
@@ -46,6 +47,12 @@ constexpr int kTileChunkMax = 4096;  // entries per pass at most (the plan's chu
 constexpr int kTileRowsMax = 16384;  // rows per block at most (local row fits the key's 14 bits)
 constexpr int kTileHead = 0x8000;    // key bit: first entry of its row in this pass
 constexpr int kTileRowMask = 0x3fff;
+// A pass that CAN be staged (pass_desc.w > 0) normally stores its entries PACKED (pass_desc.w bit 30): the column word holds
+// head << 31 | local row << 14 | (column - first staged column) and the key array is not read for it at all --
+// 4 + sizeof(T) bytes per entry, CSR's own, instead of 6 + sizeof(T).
+constexpr int kTilePassPacked = 1 << 30;  // pass_desc.w bit: the pass's entries are packed
+constexpr int kTilePackShift = 14;
+constexpr unsigned kTilePackColMask = (1u << kTilePackShift) - 1;
 constexpr int kTileTripBytes = kTileBlock * 16;  // x bytes one staging trip of the workgroup copies
 constexpr int kTileTrips = 5;        // trips per pass: windows of up to 40 KiB
 constexpr int kTileAhead = 3;        // passes whose entries are in flight beyond the one being worked on
@@ -81,11 +88,12 @@ __device__ __forceinline__ void tile_issue_entries(v4i (&rc)[CH / (4 * kTileBloc
     constexpr int kQuads = CH / (4 * kTileBlock);
     const int t = threadIdx.x;
     const int e_last = d.x + ((max(d.y, 1) - 1) & ~3);
+    const bool packed = (d.w & kTilePassPacked) != 0;  // keys ride in the column words: every lane re-reads one key quad (one line, no traffic)
 #pragma unroll
     for (int u = 0; u < kQuads; ++u) {
         const int e = min(d.x + 4 * t + u * 4 * kTileBlock, e_last);
         rc[u] = stream_load<NT>(reinterpret_cast<const v4i *>(tcol + e));
-        rk[u] = stream_load<NT>(reinterpret_cast<const v2u *>(tkey + e));
+        rk[u] = stream_load<NT>(reinterpret_cast<const v2u *>(tkey + (packed ? d.x : e)));
         rv[u] = stream_load<NT>(reinterpret_cast<const V4 *>(tval + e));
     }
 }
@@ -95,7 +103,7 @@ template <typename T, int TRIPS>
 __device__ __forceinline__ void tile_issue_window(v4u (&rw)[TRIPS], const int4 d, int stage_ok, const T *__restrict__ x) {
     constexpr int kPer = 16 / (int)sizeof(T);
     const int t = threadIdx.x;
-    const int wlen = stage_ok ? max(d.w, kPer) : kPer;
+    const int wlen = stage_ok ? max(d.w & (kTilePassPacked - 1), kPer) : kPer;
     const char *src = reinterpret_cast<const char *>(x + d.z);
 #pragma unroll
     for (int k = 0; k < TRIPS; ++k) {
@@ -176,7 +184,8 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int4 d = pass_desc[p];
     const int count = d.y, wbase = d.z;
-    const int wlen = stage_ok ? d.w : 0;
+    const int wlen = stage_ok ? (d.w & (kTilePassPacked - 1)) : 0;
+    const bool packed = (d.w & kTilePassPacked) != 0;  // (a packed pass is gathered all the same when x is not 16-byte aligned)
     if (wlen && !(probe & 1)) {  // (probe bit 0, measurement only: the slice is not written to LDS)
 #pragma unroll
         for (int k = 0; k < TRIPS; ++k) {
@@ -191,7 +200,10 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
             const int i = u * 4 * kTileBlock + 4 * t;
             // entries behind the pass's end belong to the next pass: masked out, never looked up
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xv[4 * u + q] = gather(x, i + q < count ? cc[u][q] : wbase);
+            for (int q = 0; q < 4; ++q) {
+                const int cq = packed ? wbase + (int)((unsigned)cc[u][q] & kTilePackColMask) : cc[u][q];
+                xv[4 * u + q] = gather(x, i + q < count ? cq : wbase);
+            }
         }
     }
     // (the last passes re-issue the block's last one: the count in flight stays a constant)
@@ -212,9 +224,12 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool in = i + q < count;
-            const unsigned key = (q & 1 ? ck[u][q >> 1] >> 16 : ck[u][q >> 1]) & 0xffffu;
+            const unsigned word = (unsigned)cc[u][q];
+            // key = head flag | local row: out of the column word of a packed pass, else out of the key array
+            const unsigned key = packed ? ((word >> 16) & (unsigned)kTileHead) | ((word >> kTilePackShift) & (unsigned)kTileRowMask)
+                                        : (q & 1 ? ck[u][q >> 1] >> 16 : ck[u][q >> 1]) & 0xffffu;
             T xq;
-            if (wlen) xq = xs[(in ? cc[u][q] : wbase) - wbase];
+            if (wlen) xq = xs[in ? (packed ? (int)(word & kTilePackColMask) : (int)word - wbase) : 0];
             else xq = (probe & 2) ? T(1) : xv[4 * u + q];
             const T pr = in ? cv[u][q] * xq : T(0);
             // an entry behind the pass's end closes whatever run is open and opens nothing

@@ -91,7 +91,7 @@ inline void sort_keys(std::vector<uint64_t> &keys, uint32_t key_top, int threads
 template <typename T>
 void build_range(int b0, int b1, const int *block_row, const int *row_begin, const int *row_len, const int *col,
                  const T *val, int lmax, int pos_bits, int chunk, int win_cols, int density, int inner_threads,
-                 uint32_t col_top, Part<T> &out) {
+                 uint32_t col_top, bool pack, Part<T> &out) {
     // column << 32 | local row << pos_bits | position inside the row (rows <= lmax < 2^pos_bits, local rows < 2^(32 - pos_bits))
     std::vector<uint64_t> keyed;
     const uint32_t pos_mask = (1u << pos_bits) - 1;
@@ -146,15 +146,19 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
             const int wbase = cmin & ~3;
             int wlen = ((cmax - wbase + 1) + 3) & ~3;
             wlen = std::min(wlen, ((int)col_top - wbase + kPer - 1) / kPer * kPer);
-            const bool staged = wlen <= win_cols && (long long)count * density >= wlen;
+            const bool staged = wlen <= win_cols && wlen <= (int)kTilePackColMask + 1 && (long long)count * density >= wlen;
             const int e_first = (int)out.tcol.size();
             int prev_row = -1;
             for (uint64_t k : pass) {
                 const int lrow = (int)((uint32_t)k >> pos_bits), pos = (int)((uint32_t)k & pos_mask);
                 const int e = row_begin[r0 + lrow] + pos;
-                out.tcol.push_back(col[e]);
+                const bool head = lrow != prev_row;
+                if (staged && pack)  // packed: head << 31 | local row << 14 | column - window base (the key array is not read)
+                    out.tcol.push_back((int)(((unsigned)head << 31) | ((unsigned)lrow << kTilePackShift) | (unsigned)(col[e] - wbase)));
+                else
+                    out.tcol.push_back(col[e]);
                 out.tval.push_back(val[e]);
-                out.tkey.push_back((unsigned short)(lrow | (lrow != prev_row ? kTileHead : 0)));
+                out.tkey.push_back((unsigned short)(lrow | (head ? kTileHead : 0)));
                 prev_row = lrow;
             }
             while (out.tcol.size() & 3) {  // the next pass starts on a multiple of 4
@@ -162,7 +166,7 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
                 out.tval.push_back(T(0));
                 out.tkey.push_back(0);
             }
-            out.pass_desc.push_back(int4{e_first, count, wbase, staged ? wlen : 0});
+            out.pass_desc.push_back(int4{e_first, count, wbase, staged ? (wlen | (pack ? kTilePassPacked : 0)) : 0});
             out.entries += count;
             if (staged) {
                 out.staged_entries += count;
@@ -181,7 +185,7 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
 // false: the tiles would not hold the matrix (entry offsets beyond 32 bits)
 template <typename T>
 bool tile_build(int M, int N, const int *row_begin, const int *row_len, const int *col, const T *val, int rows_per_block,
-                int lmax, int density, int chunk, bool balance, int pos_bits, TilePlan<T> &plan) {
+                int lmax, int density, int chunk, bool balance, int pos_bits, TilePlan<T> &plan, bool pack = true) {
     // the window a pass may stage: kTileTrips trips of the workgroup = 40 KiB, which with a 2048-entry chunk and
     // 2048 fp64 accumulators lets two workgroups share a CU's LDS, and with 8192 of them still fits one
     const int win_cols = kTileTrips * kTileTripBytes / (int)sizeof(T);
@@ -234,7 +238,7 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
     for (int th = 0; th < threads; ++th)
         pool.emplace_back([&, th] {
             tile_detail::build_range<T>(cut[th], cut[th + 1], plan.block_row.data(), row_begin, row_len, col, val, lmax,
-                                        pos_bits, chunk, win_cols, density, inner_threads, (uint32_t)std::max(N, 1), parts[th]);
+                                        pos_bits, chunk, win_cols, density, inner_threads, (uint32_t)std::max(N, 1), pack, parts[th]);
         });
     for (auto &th : pool) th.join();
     size_t total_entries = 0, total_passes = 0;

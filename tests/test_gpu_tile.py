@@ -37,7 +37,7 @@ class tuned:
 
     def __exit__(self, *exc):
         defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 16, "stream_kind": -1,
-                    "tile_balance": 1, "tile_long": 1}
+                    "tile_balance": 1, "tile_long": 1, "tile_pack": 1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 
@@ -89,14 +89,15 @@ def test_tile_kernel_gather_passes_uniform_columns(gpu, oracle, dtype, rows):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("pack", [1, 0])
 @pytest.mark.parametrize("mean,sigma", [(3, 1500), (30, 9000), (12, 200)])
-def test_tile_kernel_staged_passes_banded_columns(gpu, oracle, dtype, mean, sigma):
+def test_tile_kernel_staged_passes_banded_columns(gpu, oracle, dtype, mean, sigma, pack):
     rng = np.random.default_rng(mean)
     M = N = 40_000
     rp, col, val = scattered(rng, M, N, mean, sigma=sigma, dtype=dtype)
     x = rng.uniform(-1, 1, N).astype(dtype)
     y_ref = reference(oracle, rp, col, val, x, dtype)
-    with tuned(stream_tile=1, tile_rows=2048):
+    with tuned(stream_tile=1, tile_rows=2048, tile_pack=pack):
         with sp.CsrDevice(M, N, rp, col, val) as dev:
             info = dev.info()
             if info["local_blocks"]:

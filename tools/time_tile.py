@@ -61,10 +61,12 @@ for name in want:
         print(f"   gather ({sp.device.CSR_STREAM_KERNELS[info['stream_kernel']]}): {ms.mean() * 1e3:8.1f} us  "
               f"{info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  {info['algo_bytes'] / ms.mean() / 1e6 / 80:5.1f} % of 8 TB/s",
               flush=True)
-    for tr, dn, ch in [(a, b, c) for c in chunks for a in tile_rows for b in dens]:
+    packs = [int(v) for v in os.environ.get("TILE_PACK", "1").split(",")]
+    for tr, dn, ch, dn_pack in [(a, b, c, d) for c in chunks for a in tile_rows for b in dens for d in packs]:
         if True:
             set_tuning("tile_balance", int(os.environ.get("TILE_BALANCE", "1")))
             set_tuning("tile_long", int(os.environ.get("TILE_LONG", "1")))
+            set_tuning("tile_pack", dn_pack)
             set_tuning("tile_lmax", int(os.environ.get("TILE_LMAX", "1024")))
             set_tuning("stream_tile", 1)
             set_tuning("tile_rows", tr)
@@ -81,7 +83,7 @@ for name in want:
                     pm = dev.time(sp.CSR_STREAM, 2, 10, zero_y=False)
                     print(f"      probe {probe} (1 no staging, 2 no gathers, 4 no run sums): {pm.mean() * 1e3:8.1f} us", flush=True)
                     set_tuning("tile_probe", 0)
-                print(f"   tile rows={tr:5d} density={dn:3d}: {ms.mean() * 1e3:8.1f} us  {info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  "
+                print(f"   tile pack={dn_pack} rows={tr:5d} density={dn:3d}: {ms.mean() * 1e3:8.1f} us  {info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  "
                       f"{info['algo_bytes'] / ms.mean() / 1e6 / 80:5.1f} %  blocks={info['tile_blocks']} passes={info['tile_passes']} "
                       f"staged={info['tile_staged_entries'] / max(1, info['tile_entries']):.2f} split_rows={info['tile_split_rows']} "
                       f"in_tiles={info['tile_entries'] / nnz:.2f} long_rows={info['tile_long_rows']} long_items={info['tile_long_items']} in_long={info['tile_long_entries'] / nnz:.2f} format_bytes={info['stream_bytes']} upload={up:.1f}s "
