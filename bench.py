@@ -364,6 +364,35 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
                          "kernel": ("csr_stream", "csr_stream_local", "csr_stream_short")[info["stream_kernel"]],
                          "format_bytes": info["stream_bytes"] or info["algo_bytes"],
                          "us": round(float(ms.mean()) * 1e3, 2)}}
+    if which in ("road_like", "wide_band"):
+        # two of tools/matrix_zoo.py's classes without an x-window plan (the reference's own list is full of such
+        # graph / circuit matrices, result/result_cuda.csv:2-31): what the 2-D tile kernel makes of them
+        import scipy.sparse as sps
+        n, per_row, sigma = (12_000_000, 3, 2000.0) if which == "road_like" else (2_000_000, 30, 20000.0)
+        rng = np.random.default_rng(2026)
+        r = np.repeat(np.arange(n, dtype=np.int64), per_row)
+        c = np.clip(r + np.rint(rng.normal(0, sigma, len(r))).astype(np.int64), 0, n - 1)
+        a = sps.csr_matrix((rng.uniform(-1, 1, len(r)), (r, c)), shape=(n, n))
+        a.sum_duplicates()
+        a.sort_indices()
+        from sparsematrixvectormultiplication_amd.device import CSR_STREAM_KERNELS
+        with sp.CsrDevice(n, n, a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data) as dev:
+            x = rng.uniform(-1, 1, n)
+            y = dev.spmv(x, sp.CSR_AUTO)
+            lo = n // 3
+            err = float(np.max(np.abs(y[lo:lo + 50000] - (a[lo:lo + 50000] @ x))) / max(np.max(np.abs(y)), 1e-300))
+            dev.set_x(np.ones(n))
+            info = dev.info()
+            ms = dev.time(sp.CSR_AUTO, warmup, max(5, steps // 4), zero_y=True)
+        return {"workload": f"{which.replace('_', ' ')}: {per_row} per row, columns N(row, {sigma:.0f}), n = {n} fp64 CSR",
+                "rows": n, "nnz": int(a.nnz), "algo_bytes": info["algo_bytes"],
+                "auto": {"kernel": CSR_STREAM_KERNELS[info["stream_kernel"]], "us": round(float(ms.mean()) * 1e3, 1),
+                         "gflops": round(2.0 * a.nnz / (ms.mean() * 1e-3) / 1e9, 1),
+                         "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
+                         "pct_of_8TBs": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9 / 80.0, 2),
+                         "format_bytes": info["stream_bytes"],
+                         "staged_share": round(info["tile_staged_entries"] / max(1, info["tile_entries"]), 3),
+                         "max_diff_vs_scipy_on_50000_rows_over_max_y": err}}
     if which == "powerlaw_f32":
         # BASELINE configs[4] at full size on ONE GPU (the 8-GPU run is the driver's): 2^24 rows, 2.6e8 nnz, fp32
         n, row_ptr, col, val = synth.powerlaw()
@@ -726,13 +755,13 @@ def main():
             parity_failed = True
     if rank == 0 and world == 1 and not args.no_also and args.workload == "nlpkkt":
         dev.close()
-        try:
-            result["also"] = [side_measurement(sp, synth, "cant_csr", K, W),
-                              side_measurement(sp, synth, "cant_hll", K, W, cpu_sweep=not (args.no_cpu_baseline or args.no_cpu_sweep)),
-                              side_measurement(sp, synth, "fem_large_csr", K, W),
-                              side_measurement(sp, synth, "powerlaw_f32", K, W)]
-        except Exception as exc:  # side numbers must never lose the headline line
-            result["also"] = [{"error": str(exc)}]
+        result["also"] = []
+        for which in ("cant_csr", "cant_hll", "fem_large_csr", "powerlaw_f32", "road_like", "wide_band"):
+            try:  # side numbers must never lose the headline line, nor each other
+                result["also"].append(side_measurement(sp, synth, which, K, W,
+                                                       cpu_sweep=which == "cant_hll" and not (args.no_cpu_baseline or args.no_cpu_sweep)))
+            except Exception as exc:
+                result["also"].append({"workload": which, "error": str(exc)})
     if comm is not None:
         comm.close()
     if world > 1:

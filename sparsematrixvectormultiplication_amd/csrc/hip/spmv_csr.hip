@@ -119,6 +119,8 @@ template <typename T>
 struct TileBuild {
     TilePlan<T> tiles, ltiles;
     bool have_tiles = false, have_long_tiles = false, scattered = false;
+    bool packed = false;  // the ordinary tiles' stageable passes are packed (never for scattered matrices: their
+                          // passes gather, and a kernel without the decode code is the faster one there)
     std::vector<int4> tile_pieces, tile_long, lt_work;
     std::vector<int> lt_rows, lt_item_first;
 };
@@ -158,7 +160,8 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
-                                  g_tile_balance != 0, 17, tb.tiles, g_tile_pack != 0);
+                                  g_tile_balance != 0, 17, tb.tiles, g_tile_pack != 0 && !tb.scattered);
+    tb.packed = g_tile_pack != 0 && !tb.scattered;
     // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
     if (tb.have_tiles && g_stream_tile < 0 && !g_tile_long && tb.tiles.entries * 2 < nz) tb.have_tiles = false;
     if (!tb.have_tiles) return;
@@ -188,7 +191,8 @@ template <typename T>
 int tile_allow_lds() {
     static bool done = false;
     if (done) return 0;
-    const void *fns[2] = {(const void *)csr_tile<T, false, 2048, kTileTrips>, (const void *)csr_tile<T, true, 2048, kTileTrips>};
+    const void *fns[4] = {(const void *)csr_tile<T, false, 2048, kTileTrips, false>, (const void *)csr_tile<T, true, 2048, kTileTrips, false>,
+                          (const void *)csr_tile<T, false, 2048, kTileTrips, true>, (const void *)csr_tile<T, true, 2048, kTileTrips, true>};
     for (const void *fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
     return 0;
@@ -213,6 +217,7 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
             m->tile_blocks = tiles.num_blocks;
             m->tile_rows = tiles.rows_per_block;
             m->tile_chunk = tiles.chunk;
+            m->tile_packed = tb.packed;
             m->tile_lds_min = tb.scattered ? 84 * 1024 : 0;  // more than half a CU's LDS: one workgroup per CU
             m->tile_passes = (int)tiles.pass_desc.size();
             m->tile_max_win = tiles.max_win;
@@ -258,6 +263,7 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
             L.entries = ltiles.entries;
             L.padded = (long long)ltiles.tcol.size() - kTileChunkMax;
             L.staged = ltiles.staged_entries;
+            L.packed = g_tile_pack != 0;
             m->device_bytes += ltiles.tcol.size() * (6 + sizeof(T)) + ltiles.pass_desc.size() * 16 + tb.lt_work.size() * 16 +
                                tb.lt_rows.size() * 8;
         }
@@ -979,7 +985,8 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
         out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
                             4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
     else if (m->tile_blocks > 0)  // tiles: 4-byte column + 2-byte key + value per (padded) entry; rows beyond the limit as CSR
-        out->stream_bytes = (m->tile_padded + m->lt.padded) * (vb + 6) - (g_tile_pack ? 2 : 0) * (m->tile_staged + m->lt.staged) +
+        out->stream_bytes = (m->tile_padded + m->lt.padded) * (vb + 6) - (m->tile_packed ? 2 : 0) * m->tile_staged -
+                            (m->lt.packed ? 2 : 0) * m->lt.staged +
                             16LL * (m->tile_passes + m->lt.passes) +
                             4LL * m->tile_blocks + 2 * vb * (long long)m->lt.items * m->lt.rows_per_block +
                             (m->nz - m->tile_entries - m->lt.entries) * (vb + 4) + 16LL * m->tile_num_pieces +
@@ -1078,24 +1085,24 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     const bool tnt = m->nz * (long long)(sizeof(T) + 6) > (128LL << 20);
                     const int which = tnt ? 1 : 0;
                     // (more than 64 KiB of dynamic LDS: allowed for these kernels once, at upload -- tile_allow_lds)
-#define SPMV_TILE(NT, CH, TRIPS)                                                                                       \
-    hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s,      \
+#define SPMV_TILE(NT, PACK)                                                                                            \
+    hipLaunchKernelGGL((csr_tile<T, NT, 2048, kTileTrips, PACK>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s, \
                        m->tile_blocks, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,        \
                        m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval, x, y)
-                    if (which == 0) SPMV_TILE(false, 2048, kTileTrips);
-                    else SPMV_TILE(true, 2048, kTileTrips);
+                    if (m->tile_packed) { if (which) SPMV_TILE(true, true); else SPMV_TILE(false, true); }
+                    else { if (which) SPMV_TILE(true, false); else SPMV_TILE(false, false); }
 #undef SPMV_TILE
                     if (m->lt.items > 0) {
                         // the long rows' own tiles: work items -> slabs -> y (after the ordinary tiles wrote 0 there)
                         const auto &L = m->lt;
                         const size_t llds = (size_t)kTileSlotBytes + (size_t)L.rows_per_block * sizeof(T) +
                                             (stage_ok ? (size_t)L.max_win * sizeof(T) : 0);
-#define SPMV_LTILE(NT, CH, TRIPS)                                                                                      \
-    hipLaunchKernelGGL((csr_tile<T, NT, CH, TRIPS>), dim3((L.items + 7) / 8 * 8), dim3(kTileBlock), llds, s, L.items,   \
+#define SPMV_LTILE(NT, PACK)                                                                                           \
+    hipLaunchKernelGGL((csr_tile<T, NT, 2048, kTileTrips, PACK>), dim3((L.items + 7) / 8 * 8), dim3(kTileBlock), llds, s, L.items, \
                        L.rows_per_block, stage_ok, g_tile_probe, (const int4 *)L.work, (T *)L.slab, L.block_row,        \
                        L.block_pass, L.pass, L.tcol, L.tkey, (const T *)L.tval, x, y)
-                        if (which == 0) SPMV_LTILE(false, 2048, kTileTrips);
-                        else SPMV_LTILE(true, 2048, kTileTrips);
+                        if (L.packed) { if (which) SPMV_LTILE(true, true); else SPMV_LTILE(false, true); }
+                        else { if (which) SPMV_LTILE(true, false); else SPMV_LTILE(false, false); }
 #undef SPMV_LTILE
                         hipLaunchKernelGGL((tile_slab_finish<T>), dim3((L.rows + kFinishRows - 1) / kFinishRows),
                                            dim3(kFinishRows * kFinishGroups), 0, s, L.rows,

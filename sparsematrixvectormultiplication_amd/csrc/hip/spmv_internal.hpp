@@ -144,6 +144,7 @@ struct spmv_csr_dev {
     int tile_blocks = 0;              // 0: no tiles
     int tile_rows = 0;                // rows per block
     int tile_chunk = 0;               // entries per pass at most (2048)
+    bool tile_packed = false;         // stageable passes hold packed column words (kernel instantiation with the decode)
     int tile_lds_min = 0;             // LDS bytes to ask for at least (scattered matrices: one workgroup per CU)
     int tile_passes = 0;
     int tile_max_win = 0;             // widest staged window (columns)
@@ -159,6 +160,7 @@ struct spmv_csr_dev {
     struct long_tiles {
         int blocks = 0, rows = 0, rows_per_block = 0, passes = 0, items = 0, max_win = 0;
         long long entries = 0, padded = 0, staged = 0;
+        bool packed = false;
         int *block_row = nullptr, *block_pass = nullptr, *block_of_row = nullptr, *item_first = nullptr, *row_map = nullptr;
         int4 *pass = nullptr, *work = nullptr;
         int *tcol = nullptr;

@@ -79,7 +79,7 @@ template <> struct vec4v<double> { typedef double type __attribute__((ext_vector
 // last 16 bytes: one line for all of them, no extra traffic) -- so that the NUMBER of loads in flight is a
 // compile-time constant: vmcnt retires in order, and only with a known count can the wait for the current
 // pass's gathers leave the next pass's loads in flight.
-template <typename T, bool NT, int CH>
+template <typename T, bool NT, int CH, bool PACK>
 __device__ __forceinline__ void tile_issue_entries(v4i (&rc)[CH / (4 * kTileBlock)], v2u (&rk)[CH / (4 * kTileBlock)],
                                                    typename vec4v<T>::type (&rv)[CH / (4 * kTileBlock)], const int4 d,
                                                    const int *__restrict__ tcol, const unsigned short *__restrict__ tkey,
@@ -88,7 +88,8 @@ __device__ __forceinline__ void tile_issue_entries(v4i (&rc)[CH / (4 * kTileBloc
     constexpr int kQuads = CH / (4 * kTileBlock);
     const int t = threadIdx.x;
     const int e_last = d.x + ((max(d.y, 1) - 1) & ~3);
-    const bool packed = (d.w & kTilePassPacked) != 0;  // keys ride in the column words: every lane re-reads one key quad (one line, no traffic)
+    // a packed pass's keys ride in its column words: every lane re-reads one key quad (one line, no traffic)
+    const bool packed = PACK && (d.w & kTilePassPacked) != 0;
 #pragma unroll
     for (int u = 0; u < kQuads; ++u) {
         const int e = min(d.x + 4 * t + u * 4 * kTileBlock, e_last);
@@ -170,7 +171,7 @@ __device__ __forceinline__ void chain_scan(T &r, int &h, int lane) {
 // (vmcnt retires in order, so what is needed soonest goes first): its own gathers, the x slice of the NEXT pass
 // (nw; served by L2), the entries of the pass kTileAhead passes further on (fc, fk, fv; served by HBM, whose
 // latency under load is several passes long).  Past the block's last pass the loads repeat that pass.
-template <typename T, bool NT, int CH, int TRIPS>
+template <typename T, bool NT, int CH, int TRIPS, bool PACK>
 __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u (&ck)[CH / (4 * kTileBlock)],
                                           typename vec4v<T>::type (&cv)[CH / (4 * kTileBlock)], v4u (&cw)[TRIPS],
                                           v4i (&fc)[CH / (4 * kTileBlock)], v2u (&fk)[CH / (4 * kTileBlock)],
@@ -185,7 +186,8 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
     const int4 d = pass_desc[p];
     const int count = d.y, wbase = d.z;
     const int wlen = stage_ok ? (d.w & (kTilePassPacked - 1)) : 0;
-    const bool packed = (d.w & kTilePassPacked) != 0;  // (a packed pass is gathered all the same when x is not 16-byte aligned)
+    // (PACK = false: a handle whose plan packs nothing, e.g. scattered columns -- no decode code at all)
+    const bool packed = PACK && (d.w & kTilePassPacked) != 0;  // (a packed pass is gathered all the same when x is not 16-byte aligned)
     if (wlen && !(probe & 1)) {  // (probe bit 0, measurement only: the slice is not written to LDS)
 #pragma unroll
         for (int k = 0; k < TRIPS; ++k) {
@@ -207,9 +209,9 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
         }
     }
     // (the last passes re-issue the block's last one: the count in flight stays a constant)
-    if (!(probe & 8)) tile_issue_window<T, TRIPS>(nw, pass_desc[min(p + 1, p_last)], stage_ok, x);  // (probe bit 3: no x slices)
-    tile_issue_entries<T, NT, CH>(fc, fk, fv, pass_desc[min(p + kTileAhead, p_last)], tcol, tkey, tval);
-    if (!(probe & 16)) __syncthreads();  // xs is in place; everybody is done with the previous pass's wave slots
+    tile_issue_window<T, TRIPS>(nw, pass_desc[min(p + 1, p_last)], stage_ok, x);
+    tile_issue_entries<T, NT, CH, PACK>(fc, fk, fv, pass_desc[min(p + kTileAhead, p_last)], tcol, tkey, tval);
+    __syncthreads();  // xs is in place; everybody is done with the previous pass's wave slots
     // ---- a lane's quads: products, the runs that close inside the quad, the open ends
     T lead[kQuads], tail[kQuads];   // sum before the quad's first head (the whole quad without one) / from its last head on
     int tail_row[kQuads];           // local row of the run `tail` belongs to (-1: none)
@@ -258,6 +260,7 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
         T r = lead[u];
         int h = has_head[u] ? 1 : 0;
         // short rows: every lane of the wavefront holds a head, every chain ends in the next lane -- no scan
+        // short rows: where every lane of the wavefront holds a head every chain ends in the next lane -- no scan
         if (__ballot(h != 0) != ~0ull) chain_scan(r, h, lane);  // wave-uniform
         if (lane == 0) {  // what the previous wavefront's open run collects from this one, and whether it ends here
             wave_r[u * kTileWaves + wave] = r;
@@ -293,7 +296,7 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
 // pass p + 1 and the entries of passes p + 1 .. p + 3 are already on their way into registers.
 // pass = {first entry (multiple of 4), entries, first staged column (multiple of 4), staged columns (0: gather)}
 // (second launch bound = wavefronts per SIMD: two resident workgroups per CU)
-template <typename T, bool NT, int CH, int TRIPS>
+template <typename T, bool NT, int CH, int TRIPS, bool PACK>
 __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int rows_per_block,
                                                                           int stage_ok, int probe,
                                                                           const int4 *__restrict__ work, T *__restrict__ slab,
@@ -344,14 +347,14 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
         v4u wa[TRIPS], wb[TRIPS];
         const int pl = p1 - 1;
 #define SPMV_TILE_PASS(cur, fill, wcur, wnext, P)                                                                       \
-    tile_pass<T, NT, CH, TRIPS>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), wnext, P, pl, pass_desc,    \
+    tile_pass<T, NT, CH, TRIPS, PACK>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), wnext, P, pl, pass_desc,    \
                                 stage_ok, probe, acc, xs, wave_r, wave_h, tcol, tkey, tval, x)
         SPMV_TILE_ENTRY_REGS(e2);
         SPMV_TILE_ENTRY_REGS(e3);
-        tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e0), pass_desc[p0], tcol, tkey, tval);
-        tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e1), pass_desc[min(p0 + 1, pl)], tcol, tkey, tval);
+        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e0), pass_desc[p0], tcol, tkey, tval);
+        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e1), pass_desc[min(p0 + 1, pl)], tcol, tkey, tval);
         tile_issue_window<T, TRIPS>(wa, pass_desc[p0], stage_ok, x);
-        tile_issue_entries<T, NT, CH>(SPMV_TILE_ENTRY_ARGS(e2), pass_desc[min(p0 + 2, pl)], tcol, tkey, tval);
+        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e2), pass_desc[min(p0 + 2, pl)], tcol, tkey, tval);
         for (int p = p0; p < p1; p += 4) {  // wave-uniform
             SPMV_TILE_PASS(e0, e3, wa, wb, p);
             if (p + 1 < p1) SPMV_TILE_PASS(e1, e0, wb, wa, p + 1);
