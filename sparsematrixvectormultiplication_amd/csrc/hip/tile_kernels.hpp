@@ -182,6 +182,8 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
                                           const T *__restrict__ tval, const T *__restrict__ x) {
     constexpr int kQuads = CH / (4 * kTileBlock);
     constexpr int kPer = 16 / (int)sizeof(T);
+    // (the three probe bits stay run-time tests on purpose: with them folded to constants this compiler's register
+    // allocation tips over the 128-VGPR cap of two workgroups per CU -- 32-96 bytes of scratch, road 167 -> 197 us)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int4 d = pass_desc[p];
     const int count = d.y, wbase = d.z;

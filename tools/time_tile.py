@@ -78,7 +78,7 @@ for name in want:
                 y1 = dev.spmv(x, sp.CSR_STREAM)
                 err = float(np.max(np.abs(y1.astype(np.float64) - y0)) / max(np.max(np.abs(y0)), 1e-300))
                 ms = dev.time(sp.CSR_STREAM, 3, 20, zero_y=False)
-                for probe in [int(v) for v in os.environ.get("TILE_PROBE", "").split(",") if v]:
+                for probe in [int(v) for v in os.environ.get("TILE_PROBE", "").split(",") if v]:  # EXPERIMENTAL=1 builds only
                     set_tuning("tile_probe", probe)
                     pm = dev.time(sp.CSR_STREAM, 2, 10, zero_y=False)
                     print(f"      probe {probe} (1 no staging, 2 no gathers, 4 no run sums): {pm.mean() * 1e3:8.1f} us", flush=True)
