@@ -42,7 +42,8 @@ def per_product(sub, counter, products):
     profiled bench ran (a kernel that is launched twice per product -- csr_tile: ordinary tiles + long rows' tiles --
     must be added up, not averaged)."""
     acc = defaultdict(float)
-    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # the newest pass only (a merged gpurun_out/ keeps earlier runs' files beside it)
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
                 acc[row["Kernel_Name"]] += float(row["Counter_Value"])
@@ -61,13 +62,15 @@ table = {k: v for k, v in table.items() if isinstance(v, dict)}  # round-1 entri
 hits = [k for k in fetch if k.split("(")[0].split("<")[0].strip().endswith(kernel.split("<")[0])]
 if not hits:
     raise SystemExit(f"kernel {kernel} not found among {sorted(fetch)}")
-for k in hits:
-    f, w = fetch[k], write.get(k, 0.0)
-    table[f"{kernel}|{workload}"] = {
-        "bytes": int((2 * f + w) * 1024), "fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1),
-        "source": tag, "kernel_src_sha": kernel_source_sha(kernel),
-        "format_bytes": int(line["roofline"]["format_bytes_per_launch"]),
-        "blocks": int(line["config"]["workgroups"]),
-        "kernel_ms_mean_unprofiled": line["roofline"]["kernel_ms_mean"]}
-    print(f"{kernel}|{workload}: FETCH_SIZE={f:.0f} KiB WRITE_SIZE={w:.0f} KiB -> {(2 * f + w) * 1024 / 1e6:.1f} MB")
+# a kernel may run as several instantiations per product (csr_tile: ordinary tiles without the packed decode + the
+# long rows' tiles with it): their traffic adds up
+f = sum(fetch[k] for k in hits)
+w = sum(write.get(k, 0.0) for k in hits)
+table[f"{kernel}|{workload}"] = {
+    "bytes": int((2 * f + w) * 1024), "fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1),
+    "source": tag, "kernel_src_sha": kernel_source_sha(kernel),
+    "format_bytes": int(line["roofline"]["format_bytes_per_launch"]),
+    "blocks": int(line["config"]["workgroups"]), "instantiations": len(hits),
+    "kernel_ms_mean_unprofiled": line["roofline"]["kernel_ms_mean"]}
+print(f"{kernel}|{workload}: FETCH_SIZE={f:.0f} KiB WRITE_SIZE={w:.0f} KiB -> {(2 * f + w) * 1024 / 1e6:.1f} MB ({len(hits)} instantiation(s))")
 json.dump(table, open(out_path, "w"), indent=1, sort_keys=True)
