@@ -66,12 +66,17 @@ KERNEL_SOURCES = {  # the file a kernel's code lives in: a traffic measurement b
 
 
 def kernel_source_sha(kernel):
+    """sha of the kernel's source with // comments and white space removed: an edited comment does not unstamp a
+    measurement, any change of code does."""
     import hashlib
+    import re
     path = KERNEL_SOURCES["hll" if kernel.startswith("hll") else "tile" if kernel == "csr_tile" else "csr"]
     try:
-        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+        text = open(path, encoding="utf-8", errors="replace").read()
     except OSError:
         return None
+    code = re.sub(r"\s+", "", re.sub(r"//[^\n]*", "", text))
+    return hashlib.sha256(code.encode()).hexdigest()[:16]
 
 
 def measured_traffic(kernel, workload, format_bytes, blocks, table_path=None):

@@ -11,23 +11,27 @@
 //   * rows are cut into ROW BLOCKS of consecutive rows (at most `rows_per_block`, about equally many
 //     entries each); one workgroup owns a block and keeps its y values as accumulators in LDS for the
 //     whole kernel;
-//   * the block's entries are re-ordered at upload into PASSES = consecutive column ranges of at most
-//     `chunk` (2048 or 4096) entries, and inside a pass by (row, column).  All workgroups start at column 0 and
-//     sweep upwards together, so at any moment the chip gathers from a narrow band of x that stays
-//     in L2 (the L2-sized column stripes of a DCSR scheme, without per-stripe row lists or partial
-//     sums in memory: the accumulators never leave LDS);
+//   * the block's entries are re-ordered at upload into PASSES = consecutive column ranges of at most 2048
+//     entries, and inside a pass by (row, column).  All workgroups start at column 0 and sweep upwards
+//     together -- equal work per block keeps them in step -- so at any moment the chip gathers from a
+//     narrow band of x that stays in L2 (the L2-sized column stripes of a DCSR scheme, without per-stripe
+//     row lists or partial sums in memory: the accumulators never leave LDS).  Measured on the power-law
+//     matrix: 2.9 cycles per gathered value and CU when the blocks are in step and a pass spans <= 2 MB of
+//     x, against 7-8 when they are not;
 //   * a pass whose column range is narrow and dense enough is STAGED: its slice of x is copied into
 //     LDS with full-width coalesced loads and the per-entry lookups become ds_reads (the x-window
 //     idea with a dense window instead of a line list);
-//   * inside a pass an entry carries a key {head flag, local row} -- 16 bits beside a 32-bit column, or, in a
-//     pass that can be staged, packed with the column's offset in the slice into one 32-bit word -- and every lane holds FOUR
-//     CONSECUTIVE entries, so most of a row's run is added up in registers: runs that begin and end
-//     inside a lane go straight to the accumulator; a run that crosses lanes is finished by a
-//     right-to-left segmented scan over the lanes' leading partial sums (ds_bpermute inside a
-//     wavefront, one LDS slot per wavefront across them) and added by the lane that holds its head.
-//     One owner per (row, pass), passes in order, a fixed reduction tree: no atomics, the same bits
-//     on every launch.  Rows longer than the plan's limit (16 Ki entries) stay with the split-row
-//     kernels, their pieces cut at L2-sized column stripes and launched stripe by stripe.
+//   * inside a pass an entry carries a key {head flag, local row} -- 16 bits beside a 32-bit column, or,
+//     in a pass that can be staged, packed with the column's offset in the slice into one 32-bit word --
+//     and every lane holds FOUR CONSECUTIVE entries, so most of a row's run is added up in registers:
+//     runs that begin and end inside a lane go straight to the accumulator; a run that crosses lanes is
+//     finished by a right-to-left segmented scan over the lanes' leading partial sums (DPP row shifts and
+//     v_readlane inside a wavefront, skipped where every lane holds a head; one LDS slot per wavefront
+//     across them) and added by the lane that holds its head.  One owner per (row, pass), passes in order,
+//     a fixed reduction tree: no atomics, the same bits on every launch;
+//   * rows longer than the plan's limit (1024 entries) are compacted into row blocks of their own, whose
+//     column ranges hold so many entries that every pass is staged; such a block's passes are dealt out to
+//     many workgroups (work items), each leaves its accumulators in a slab, tile_slab_finish adds them.
 //
 // No reference counterpart (its CUDA kernels gather x per entry, cuda_src/csr_matrix_cuda.cu:122-241).
 #pragma once
@@ -43,7 +47,7 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 constexpr int kTileBlock = 512;      // threads per workgroup (8 wavefronts)
 constexpr int kTileWaves = kTileBlock / 64;
-constexpr int kTileChunkMax = 4096;  // entries per pass at most (the plan's chunk is 2048 or 4096)
+constexpr int kTileChunkMax = 4096;  // padding behind the entry arrays (the plan's chunk, entries per pass at most, is 2048)
 constexpr int kTileRowsMax = 16384;  // rows per block at most (local row fits the key's 14 bits)
 constexpr int kTileHead = 0x8000;    // key bit: first entry of its row in this pass
 constexpr int kTileRowMask = 0x3fff;
