@@ -98,6 +98,7 @@ typedef struct {
                                       a block's passes dealt out to many workgroups, slabs added in order) */
     int tile_long_items;           /* CSR: workgroups of that plan */
     long long tile_long_entries;   /* CSR: entries it holds */
+    long long tile_staged_cols;    /* CSR: x values the staged passes copy to LDS per SpMV (all tile plans): traffic served by L2 */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -164,8 +165,11 @@ int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx
 /* The same for the csr_tile plan (row blocks x column passes, see spmv_dev_info.tile_*): builds it as upload
  * would with the given parameters (rows per block: multiple of 256 in 256..16384; lmax: longest row kept in the
  * tiles; density: columns per entry up to which a pass is staged; chunk: 2048 entries per pass; balance: 1 = row blocks of about equal entry counts) and replays the kernel's bookkeeping with
- * integer checksums; needs no device.  stats[6] (optional): row blocks, passes, entries in tiles, entries in
- * staged passes, rows left to the split-row kernels, widest staged window (columns). */
+ * integer checksums; needs no device.  Both kinds of plan are built and checked: the one with gather passes, then
+ * the PACKED one (every pass cut at the window and staged, column words carry the keys: what upload builds for
+ * banded matrices, run by the kernel instantiation without gather code).  stats[12] (optional), six per kind in
+ * that order: row blocks, passes, entries in tiles, entries in staged passes, rows left to the split-row
+ * kernels, widest staged window (columns). */
 int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
                                  int rows_per_block, int lmax, int density, int chunk, int balance, long long *stats);
 /* COO triplets (0-based, any order) -> a CSR handle, built ON THE DEVICE (upload of the

@@ -82,7 +82,7 @@ void build_striped_pieces(int M, const int *rp, const int *col, const std::vecto
 template <typename T>
 bool build_long_tiles(int M, int N, const int *rp, const int *row_len, const int *col, const T *val, int chunk,
                       std::vector<unsigned char> &split, TilePlan<T> &plan, std::vector<int> &rows,
-                      std::vector<int4> &work, std::vector<int> &item_first) {
+                      std::vector<int4> &work, std::vector<int> &item_first, bool &packed) {
     constexpr int kPosBits = 21, kRowsPerBlock = 2048;  // rows of up to 2^21 - 1 entries, 2048 of them per block
     rows.clear();
     long long entries = 0;
@@ -97,9 +97,17 @@ bool build_long_tiles(int M, int N, const int *rp, const int *row_len, const int
         vbegin[v] = rp[rows[v]];
         vlen[v] = row_len[rows[v]];
     }
+    // packed (every pass staged) unless that leaves passes of a few entries each
+    packed = g_tile_pack != 0;
     if (!tile_build<T>((int)rows.size(), N, vbegin.data(), vlen.data(), col, val, kRowsPerBlock, (1 << kPosBits) - 1,
-                       g_tile_density, chunk, true, kPosBits, plan, g_tile_pack != 0))
+                       g_tile_density, chunk, true, kPosBits, plan, packed))
         return false;
+    if (packed && plan.entries < (long long)plan.pass_desc.size() * (chunk / 8)) {
+        packed = false;
+        if (!tile_build<T>((int)rows.size(), N, vbegin.data(), vlen.data(), col, val, kRowsPerBlock, (1 << kPosBits) - 1,
+                           g_tile_density, chunk, true, kPosBits, plan, false))
+            return false;
+    }
     for (int r : rows) split[(size_t)r] = 0;
     // work items: ~4096 of them over all blocks, at least 4 passes each
     const long long passes = (long long)plan.pass_desc.size();
@@ -119,8 +127,8 @@ template <typename T>
 struct TileBuild {
     TilePlan<T> tiles, ltiles;
     bool have_tiles = false, have_long_tiles = false, scattered = false;
-    bool packed = false;  // the ordinary tiles' stageable passes are packed (never for scattered matrices: their
-                          // passes gather, and a kernel without the decode code is the faster one there)
+    bool packed = false;     // the ordinary tiles are a packed plan: every pass staged (never for scattered matrices)
+    bool lt_packed = false;  // ... the long rows' tiles
     std::vector<int4> tile_pieces, tile_long, lt_work;
     std::vector<int> lt_rows, lt_item_first;
 };
@@ -144,24 +152,40 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     const int chunk = 2048;
     int rb = g_tile_rows;
     const int density = g_tile_density;
-    if (!rb) {
-        const int banded_rows = 32768 / (int)sizeof(T);
+    // Which kernel: a plan most of whose entries sit in passes dense enough to stage (>= 90 % on the sample) is built
+    // PACKED -- every pass cut at the window and staged, the sparse tails too (tile_plan.hpp) -- for the kernel
+    // instantiation without gather code; anything else keeps gather passes.
+    const int banded_rows = 32768 / (int)sizeof(T);
+    bool want_pack = g_tile_pack != 0;
+    {
         // a slice of the matrix from its middle (rows keep their global columns)
-        const int sample = std::min(Ml, 8 * banded_rows), s0 = (Ml - sample) / 2;
+        const int srows = rb ? rb : banded_rows;
+        const int sample = std::min(Ml, 8 * srows), s0 = (Ml - sample) / 2;
         TilePlan<T> probe;
-        const bool ok = tile_build<T>(sample, N, row_begin + s0, row_len + s0, hcol, hval, banded_rows, g_tile_lmax, density,
-                                      chunk, g_tile_balance != 0, 17, probe, g_tile_pack != 0);
-        if (ok && probe.staged_entries * 2 >= probe.entries) {
-            rb = banded_rows;
-        } else {
-            rb = 16384;
-            while (rb > 2048 && (long long)Ml < 448LL * rb) rb >>= 1;  // at least ~1.75 blocks per CU
-            tb.scattered = true;
+        const bool ok = tile_build<T>(sample, N, row_begin + s0, row_len + s0, hcol, hval, srows, g_tile_lmax, density,
+                                      chunk, g_tile_balance != 0, 17, probe, false);
+        const bool banded = ok && probe.staged_entries * 2 >= probe.entries;
+        want_pack = want_pack && ok && probe.staged_entries * 10 >= probe.entries * 9;
+        if (!rb) {
+            if (banded) {
+                rb = banded_rows;
+            } else {
+                rb = 16384;
+                while (rb > 2048 && (long long)Ml < 448LL * rb) rb >>= 1;  // at least ~1.75 blocks per CU
+                tb.scattered = true;
+            }
         }
     }
+    tb.packed = want_pack && !tb.scattered;
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
-                                  g_tile_balance != 0, 17, tb.tiles, g_tile_pack != 0 && !tb.scattered);
-    tb.packed = g_tile_pack != 0 && !tb.scattered;
+                                  g_tile_balance != 0, 17, tb.tiles, tb.packed);
+    // (outliers far from the band can leave a packed plan with passes of a few entries each: if they get out of
+    // hand -- fewer than chunk / 8 entries per pass on average -- the plan with gather passes is the better one)
+    if (tb.have_tiles && tb.packed && tb.tiles.entries < (long long)tb.tiles.pass_desc.size() * (chunk / 8)) {
+        tb.packed = false;
+        tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
+                                      g_tile_balance != 0, 17, tb.tiles, false);
+    }
     // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
     if (tb.have_tiles && g_stream_tile < 0 && !g_tile_long && tb.tiles.entries * 2 < nz) tb.have_tiles = false;
     if (!tb.have_tiles) return;
@@ -171,7 +195,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     std::vector<unsigned char> leftover = tb.tiles.split;
     if (g_tile_long)
         tb.have_long_tiles = build_long_tiles<T>(Ml, N, row_begin, row_len, hcol, hval, chunk, leftover, tb.ltiles, tb.lt_rows,
-                                                 tb.lt_work, tb.lt_item_first);
+                                                 tb.lt_work, tb.lt_item_first, tb.lt_packed);
     bool any_left = false;
     for (unsigned char f : leftover) any_left |= f != 0;
     if (!any_left) return;
@@ -227,7 +251,7 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
             m->tile_padded = (long long)tiles.tcol.size() - kTileChunkMax;
             m->tile_num_long = (int)tb.tile_long.size();
             m->tile_num_pieces = (int)tb.tile_pieces.size();
-            m->device_bytes += tiles.tcol.size() * (6 + sizeof(T)) + tiles.pass_desc.size() * 16 + tiles.block_pass.size() * 4 +
+            m->device_bytes += tiles.tcol.size() * (4 + sizeof(T)) + tiles.tkey.size() * 2 + tiles.pass_desc.size() * 16 + tiles.block_pass.size() * 4 +
                                (tb.tile_pieces.size() + tb.tile_long.size()) * 16;
         }
     }
@@ -263,8 +287,9 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
             L.entries = ltiles.entries;
             L.padded = (long long)ltiles.tcol.size() - kTileChunkMax;
             L.staged = ltiles.staged_entries;
-            L.packed = g_tile_pack != 0;
-            m->device_bytes += ltiles.tcol.size() * (6 + sizeof(T)) + ltiles.pass_desc.size() * 16 + tb.lt_work.size() * 16 +
+            L.staged_cols = ltiles.staged_cols;
+            L.packed = tb.lt_packed;
+            m->device_bytes += ltiles.tcol.size() * (4 + sizeof(T)) + ltiles.tkey.size() * 2 + ltiles.pass_desc.size() * 16 + tb.lt_work.size() * 16 +
                                tb.lt_rows.size() * 8;
         }
     }
@@ -726,18 +751,18 @@ extern "C" int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const i
 // exactly as upload does and (1) verifies the structural invariants the kernel relies on (aligned passes
 // within the chunk, ascending rows with a head flag on every row's first entry, staged columns inside the
 // window, passes walking the columns upwards), (2) adds an integer checksum per entry into its row's
-// accumulator and compares every row with the checksum of its entries taken straight from the CSR arrays.  stats (optional, 6 values): blocks,
-// passes, entries in tiles, entries in staged passes, rows left to the split-row kernels, widest window.
+// accumulator and compares every row with the checksum of its entries taken straight from the CSR arrays.  stats (optional, 6 values per
+// plan kind): blocks, passes, entries in tiles, entries in staged passes, rows left to the split-row kernels, widest window.
 template <typename T>
 static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows_per_block, int lmax, int density,
-                           int chunk, int balance, long long *stats) {
+                           int chunk, int balance, bool pack, long long *stats) {
     const long long nz = rp[M];
     std::vector<T> val((size_t)nz);
     for (long long e = 0; e < nz; ++e) val[(size_t)e] = (T)(1 + e % 7);
     TilePlan<T> plan;
     std::vector<int> row_len((size_t)M);
     for (int r = 0; r < M; ++r) row_len[(size_t)r] = rp[r + 1] - rp[r];
-    if (!tile_build<T>(M, N, rp, row_len.data(), col, val.data(), rows_per_block, lmax, density, chunk, balance != 0, 17, plan))
+    if (!tile_build<T>(M, N, rp, row_len.data(), col, val.data(), rows_per_block, lmax, density, chunk, balance != 0, 17, plan, pack))
         return fail("tile_plan_check: the plan does not fit 32-bit entry offsets");
     const int win_cols = plan.win_cols;
     auto h = [](long long c, double v) { return (unsigned long long)(c + 1) * 0x9E3779B97F4A7C15ull + (unsigned long long)v; };
@@ -756,6 +781,8 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
             const int count = d.y, wbase = d.z, wlen = d.w & (kTilePassPacked - 1);
             const bool packed = (d.w & kTilePassPacked) != 0;
             if (packed && !wlen) return fail("tile_plan_check: pass %d is packed without a window", p);
+            // a packed plan is for the kernel without gather code: every pass staged and packed, no key array
+            if (packed != pack) return fail("tile_plan_check: pass %d of a %s plan is %s", p, pack ? "packed" : "plain", packed ? "packed" : "not");
             constexpr int kPer = 16 / (int)sizeof(T);
             if (count <= 0 || count > chunk || (d.x & 3) || (wbase & 3) || (wlen % kPer) || wlen < 0)
                 return fail("tile_plan_check: pass %d is malformed", p);
@@ -770,7 +797,6 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
                 const int c = packed ? wbase + (int)(word & kTilePackColMask) : (int)word;
                 const unsigned key = packed ? ((word >> 16) & (unsigned)kTileHead) | ((word >> kTilePackShift) & (unsigned)kTileRowMask)
                                             : plan.tkey[(size_t)d.x + i];
-                if (packed && key != plan.tkey[(size_t)d.x + i]) return fail("tile_plan_check: packed key of entry %d in pass %d is wrong", i, p);
                 const int lrow = (int)(key & kTileRowMask);
                 if ((unsigned)c >= (unsigned)N || lrow >= nrows) return fail("tile_plan_check: entry %d of pass %d is out of range", i, p);
                 if (wlen && (c < wbase || c >= wbase + wlen)) return fail("tile_plan_check: staged pass %d misses column %d", p, c);
@@ -853,9 +879,15 @@ extern "C" int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, co
         if (row_ptr[r + 1] < row_ptr[r]) return fail("tile_plan_check: row_ptr decreases at row %d", r);
     for (long long e = 0; e < nz; ++e)
         if ((unsigned)col_idx[e] >= (unsigned)N) return fail("tile_plan_check: column %d outside [0, %d)", col_idx[e], N);
+    // both kinds of plan: with gather passes (the stats are this one's) and packed (every pass staged)
     return guarded("tile_plan_check", [&] {
-        return value_bytes == 8 ? tile_plan_check<double>(M, N, row_ptr, col_idx, rows_per_block, lmax, density, chunk, balance, stats)
-                                : tile_plan_check<float>(M, N, row_ptr, col_idx, rows_per_block, lmax, density, chunk, balance, stats);
+        for (int pack = 0; pack < 2; ++pack) {
+            long long *st = pack ? (stats ? stats + 6 : nullptr) : stats;
+            const int rc = value_bytes == 8 ? tile_plan_check<double>(M, N, row_ptr, col_idx, rows_per_block, lmax, density, chunk, balance, pack != 0, st)
+                                            : tile_plan_check<float>(M, N, row_ptr, col_idx, rows_per_block, lmax, density, chunk, balance, pack != 0, st);
+            if (rc) return rc;
+        }
+        return 0;
     });
 }
 
@@ -977,6 +1009,7 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->tile_split_rows = m->tile_num_long;
     out->tile_long_rows = m->lt.rows;
     out->tile_long_entries = m->lt.entries;
+    out->tile_staged_cols = m->tile_staged_cols + m->lt.staged_cols;
     out->tile_long_items = m->lt.items;
     out->stream_kernel = m->local_blocks > 0 ? 1 : m->tile_blocks > 0 ? 3
                          : ((m->stream_cap == 4096 || m->stream_cap == 2048) && m->M_local > 0 &&
@@ -1077,11 +1110,14 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                                    (g_stream_kind == -1 || g_stream_kind == 6 || m->tiles_only);
                 if (m->tiles_only && !tiled) return fail("csr_launch: a tiles-only handle has nothing else to run");
                 if (tiled) {
-                    // staging copies 16-byte pieces of x
+                    // staging copies 16-byte pieces of x: plans with gather passes fall back on gathering everything when
+                    // x is not 16-byte aligned, packed plans (no gather code) load the pieces unaligned
                     const int stage_ok = ((uintptr_t)x & 15) == 0;
-                    const size_t lds = std::max((size_t)m->tile_lds_min,
+                    // (probe bit 3, measurement only: one workgroup per CU)
+                    const size_t lds = std::max((size_t)std::max(m->tile_lds_min, g_tile_probe & 8 ? 84 * 1024 : 0),
                                                 (size_t)kTileSlotBytes + (size_t)m->tile_rows * sizeof(T) +
-                                                    (stage_ok ? (size_t)m->tile_max_win * sizeof(T) : 0));
+                                                    (m->tile_packed ? (size_t)kTileTrips * kTileTripBytes  // (the packed kernel stores every trip's piece)
+                                                                    : stage_ok ? (size_t)m->tile_max_win * sizeof(T) : 0));
                     const bool tnt = m->nz * (long long)(sizeof(T) + 6) > (128LL << 20);
                     const int which = tnt ? 1 : 0;
                     // (more than 64 KiB of dynamic LDS: allowed for these kernels once, at upload -- tile_allow_lds)
@@ -1096,7 +1132,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                         // the long rows' own tiles: work items -> slabs -> y (after the ordinary tiles wrote 0 there)
                         const auto &L = m->lt;
                         const size_t llds = (size_t)kTileSlotBytes + (size_t)L.rows_per_block * sizeof(T) +
-                                            (stage_ok ? (size_t)L.max_win * sizeof(T) : 0);
+                                            (L.packed ? (size_t)kTileTrips * kTileTripBytes : stage_ok ? (size_t)L.max_win * sizeof(T) : 0);
 #define SPMV_LTILE(NT, PACK)                                                                                           \
     hipLaunchKernelGGL((csr_tile<T, NT, 2048, kTileTrips, PACK>), dim3((L.items + 7) / 8 * 8), dim3(kTileBlock), llds, s, L.items, \
                        L.rows_per_block, stage_ok, g_tile_probe, (const int4 *)L.work, (T *)L.slab, L.block_row,        \

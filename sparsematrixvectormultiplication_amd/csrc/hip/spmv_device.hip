@@ -181,7 +181,7 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "tile_balance")) {
         g_tile_balance = value != 0;
     } else if (!strcmp(key, "tile_probe")) {
-        g_tile_probe = value & 7;
+        g_tile_probe = value & 15;
     } else if (!strcmp(key, "tile_density")) {
         if (value < 0 || value > 4096) return fail("set_tuning: tile_density must be 0 (never stage) .. 4096");
         g_tile_density = value;

@@ -48,7 +48,7 @@ extern int g_pipe_wgs_per_cu; // resident workgroups per CU the persistent grids
 extern int g_stream_tile;     // csr_tile plan at upload: -1 = auto (no x-window plan, enough rows), 0 = never, 1 = whenever no x-window plan
 extern int g_tile_rows;       // rows per block: 0 = auto, else a power of two in 256..8192
 extern int g_tile_lmax;       // rows longer than this stay with the split-row kernels
-extern int g_tile_probe;      // measurement only: bit 0 no LDS staging, bit 1 no gathers, bit 2 no run sums (y is then wrong)
+extern int g_tile_probe;      // measurement only: bit 0 loads, staging and barriers only, bit 1 no gathers, bit 2 no run sums (y is then wrong), bit 3 one workgroup per CU
 extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keeps the workgroups in step), 0: equal row counts
 extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile plan of their own (compacted rows, work items, slabs)
 extern int g_tile_pack;       // 1: passes that can be staged store head | row | column offset in one 32-bit word (no key read)
@@ -159,7 +159,7 @@ struct spmv_csr_dev {
     // are dealt out to several workgroups (work items), each leaves its accumulators in a slab
     struct long_tiles {
         int blocks = 0, rows = 0, rows_per_block = 0, passes = 0, items = 0, max_win = 0;
-        long long entries = 0, padded = 0, staged = 0;
+        long long entries = 0, padded = 0, staged = 0, staged_cols = 0;
         bool packed = false;
         int *block_row = nullptr, *block_pass = nullptr, *block_of_row = nullptr, *item_first = nullptr, *row_map = nullptr;
         int4 *pass = nullptr, *work = nullptr;

@@ -92,13 +92,12 @@ __device__ __forceinline__ void tile_issue_entries(v4i (&rc)[CH / (4 * kTileBloc
     constexpr int kQuads = CH / (4 * kTileBlock);
     const int t = threadIdx.x;
     const int e_last = d.x + ((max(d.y, 1) - 1) & ~3);
-    // a packed pass's keys ride in its column words: every lane re-reads one key quad (one line, no traffic)
-    const bool packed = PACK && (d.w & kTilePassPacked) != 0;
 #pragma unroll
     for (int u = 0; u < kQuads; ++u) {
         const int e = min(d.x + 4 * t + u * 4 * kTileBlock, e_last);
         rc[u] = stream_load<NT>(reinterpret_cast<const v4i *>(tcol + e));
-        rk[u] = stream_load<NT>(reinterpret_cast<const v2u *>(tkey + (packed ? d.x : e)));
+        // (a packed plan's keys ride in its column words: the key array is not read at all)
+        if constexpr (!PACK) rk[u] = stream_load<NT>(reinterpret_cast<const v2u *>(tkey + e));
         rv[u] = stream_load<NT>(reinterpret_cast<const V4 *>(tval + e));
     }
 }
@@ -171,53 +170,70 @@ __device__ __forceinline__ void chain_scan(T &r, int &h, int lane) {
     }
 }
 
-// One pass.  (cc, ck, cv) and cw hold its entries and its x slice; the loads this pass sends out, in this order
-// (vmcnt retires in order, so what is needed soonest goes first): its own gathers, the x slice of the NEXT pass
-// (nw; served by L2), the entries of the pass kTileAhead passes further on (fc, fk, fv; served by HBM, whose
-// latency under load is several passes long).  Past the block's last pass the loads repeat that pass.
+// One pass.  (cc, ck, cv) and cw hold its entries and its x slice; the loads this pass sends out, in this order:
+// its own gathers, the x slice of the pass AFTER THE NEXT (back into cw, whose contents have just gone to LDS; the
+// next pass's slice is in flight in the other register set), the entries of the pass kTileAhead passes further on
+// (fc, fk, fv).  vmcnt retires in order: the wait for a slice at the top of a pass drains everything sent out
+// before that slice, so what stays in flight across the wait is what was sent out after it -- with the slice one
+// pass ahead that was ONE pass's entries per workgroup (24 KB; 4.1-4.4 TB/s for the bare stream of entries), with
+// it two passes ahead it is two.  Past the block's last pass the loads repeat that pass.
 template <typename T, bool NT, int CH, int TRIPS, bool PACK>
 __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u (&ck)[CH / (4 * kTileBlock)],
                                           typename vec4v<T>::type (&cv)[CH / (4 * kTileBlock)], v4u (&cw)[TRIPS],
                                           v4i (&fc)[CH / (4 * kTileBlock)], v2u (&fk)[CH / (4 * kTileBlock)],
-                                          typename vec4v<T>::type (&fv)[CH / (4 * kTileBlock)], v4u (&nw)[TRIPS],
-                                          int p, int p_last, const int4 *__restrict__ pass_desc, int stage_ok,
+                                          typename vec4v<T>::type (&fv)[CH / (4 * kTileBlock)],
+                                          const int4 d, const int4 dw, const int4 de, bool live, int stage_ok,
                                           int probe, T *acc, T *xs, T *wave_r, int *wave_h,
                                           const int *__restrict__ tcol, const unsigned short *__restrict__ tkey,
                                           const T *__restrict__ tval, const T *__restrict__ x) {
     constexpr int kQuads = CH / (4 * kTileBlock);
     constexpr int kPer = 16 / (int)sizeof(T);
-    // (the three probe bits stay run-time tests on purpose: with them folded to constants this compiler's register
+    // (the probe bits stay run-time tests on purpose: with them folded to constants this compiler's register
     // allocation tips over the 128-VGPR cap of two workgroups per CU -- 32-96 bytes of scratch, road 167 -> 197 us)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int4 d = pass_desc[p];
-    const int count = d.y, wbase = d.z;
-    const int wlen = stage_ok ? (d.w & (kTilePassPacked - 1)) : 0;
-    // (PACK = false: a handle whose plan packs nothing, e.g. scattered columns -- no decode code at all)
-    const bool packed = PACK && (d.w & kTilePassPacked) != 0;  // (a packed pass is gathered all the same when x is not 16-byte aligned)
-    if (wlen && !(probe & 1)) {  // (probe bit 0, measurement only: the slice is not written to LDS)
+    // d / dw / de: the descriptors of this pass, of the pass whose slice goes out now (two on) and of the pass whose
+    // entries go out now (three on), fetched by the caller a pass early: three dependent scalar loads at the top of
+    // every pass were on each wavefront's critical path.  live = false: a pass behind the block's last one (the loop
+    // below always runs four), which repeats it with no entries
+    const int count = live ? d.y : 0, wbase = d.z;
+    // PACK: a plan all of whose passes are staged and packed (tile_plan.hpp cuts every pass at the window) -- no
+    // gather, no key array, and the same loads in every pass whatever it holds
+    const int wlen = PACK ? max(d.w & (kTilePassPacked - 1), kPer) : stage_ok ? (d.w & (kTilePassPacked - 1)) : 0;
+    if constexpr (PACK) {
+        // every piece is stored, needed or not, each to its own place (the launch gives xs room for all TRIPS trips): a
+        // store the compiler may skip leaves its load pending on that path, and the next write to those registers
+        // then waits for it -- and for everything sent out before it
+#pragma unroll
+        for (int k = 0; k < TRIPS; ++k) *reinterpret_cast<v4u *>(xs + (k * kTileBlock + t) * kPer) = cw[k];
+        // (the reload of cw below stays behind these stores: hoisted above them it lands in a third register set)
+        __builtin_amdgcn_sched_barrier(0);
+    } else if (wlen) {
 #pragma unroll
         for (int k = 0; k < TRIPS; ++k) {
             const int j = min((k * kTileBlock + t) * kPer, wlen - kPer);  // (the same bytes to the same place)
             if (k * kTileBlock * kPer < wlen) *reinterpret_cast<v4u *>(xs + j) = cw[k];
         }
     }
-    T xv[4 * kQuads];
-    if (!wlen && !(probe & 2)) {  // gathers go out first (vmcnt retires in order): they are back when the barrier opens
+    T xv[PACK ? 1 : 4 * kQuads];
+    if constexpr (!PACK) {
+        if (!wlen && !(probe & 2)) {  // gathers go out first (vmcnt retires in order): they are back when the barrier opens
 #pragma unroll
-        for (int u = 0; u < kQuads; ++u) {
-            const int i = u * 4 * kTileBlock + 4 * t;
-            // entries behind the pass's end belong to the next pass: masked out, never looked up
+            for (int u = 0; u < kQuads; ++u) {
+                const int i = u * 4 * kTileBlock + 4 * t;
+                // entries behind the pass's end belong to the next pass: masked out, never looked up
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cq = packed ? wbase + (int)((unsigned)cc[u][q] & kTilePackColMask) : cc[u][q];
-                xv[4 * u + q] = gather(x, i + q < count ? cq : wbase);
+                for (int q = 0; q < 4; ++q) xv[4 * u + q] = gather(x, i + q < count ? cc[u][q] : wbase);
             }
         }
     }
     // (the last passes re-issue the block's last one: the count in flight stays a constant)
-    tile_issue_window<T, TRIPS>(nw, pass_desc[min(p + 1, p_last)], stage_ok, x);
-    tile_issue_entries<T, NT, CH, PACK>(fc, fk, fv, pass_desc[min(p + kTileAhead, p_last)], tcol, tkey, tval);
+    tile_issue_window<T, TRIPS>(cw, dw, PACK ? 1 : stage_ok, x);
+    tile_issue_entries<T, NT, CH, PACK>(fc, fk, fv, de, tcol, tkey, tval);
     __syncthreads();  // xs is in place; everybody is done with the previous pass's wave slots
+    if (probe & 1) {  // (measurement only: loads, staging and barriers, nothing else)
+        __syncthreads();
+        return;
+    }
     // ---- a lane's quads: products, the runs that close inside the quad, the open ends
     T lead[kQuads], tail[kQuads];   // sum before the quad's first head (the whole quad without one) / from its last head on
     int tail_row[kQuads];           // local row of the run `tail` belongs to (-1: none)
@@ -233,12 +249,17 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
         for (int q = 0; q < 4; ++q) {
             const bool in = i + q < count;
             const unsigned word = (unsigned)cc[u][q];
-            // key = head flag | local row: out of the column word of a packed pass, else out of the key array
-            const unsigned key = packed ? ((word >> 16) & (unsigned)kTileHead) | ((word >> kTilePackShift) & (unsigned)kTileRowMask)
-                                        : (q & 1 ? ck[u][q >> 1] >> 16 : ck[u][q >> 1]) & 0xffffu;
+            // key = head flag | local row: out of the column word of a packed plan, else out of the key array
+            unsigned key;
             T xq;
-            if (wlen) xq = xs[in ? (packed ? (int)(word & kTilePackColMask) : (int)word - wbase) : 0];
-            else xq = (probe & 2) ? T(1) : xv[4 * u + q];
+            if constexpr (PACK) {
+                key = ((word >> 16) & (unsigned)kTileHead) | ((word >> kTilePackShift) & (unsigned)kTileRowMask);
+                xq = xs[in ? (int)(word & kTilePackColMask) : 0];
+            } else {
+                key = (q & 1 ? ck[u][q >> 1] >> 16 : ck[u][q >> 1]) & 0xffffu;
+                if (wlen) xq = xs[in ? (int)word - wbase : 0];
+                else xq = (probe & 2) ? T(1) : xv[4 * u + q];
+            }
             const T pr = in ? cv[u][q] * xq : T(0);
             // an entry behind the pass's end closes whatever run is open and opens nothing
             if (!in || (key & kTileHead)) {
@@ -298,8 +319,8 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
     // wave slots only behind its own first barrier, which every lane reaches after this point
 }
 
-// One workgroup per row block; passes software-pipelined: while pass p is multiplied and summed, the x slice of
-// pass p + 1 and the entries of passes p + 1 .. p + 3 are already on their way into registers.
+// One workgroup per row block; passes software-pipelined: while pass p is multiplied and summed, the x slices of
+// passes p + 1, p + 2 and the entries of passes p + 1 .. p + 3 are already on their way into registers.
 // pass = {first entry (multiple of 4), entries, first staged column (multiple of 4), staged columns (0: gather)}
 // (second launch bound = wavefronts per SIMD: two resident workgroups per CU)
 template <typename T, bool NT, int CH, int TRIPS, bool PACK>
@@ -352,20 +373,68 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
         SPMV_TILE_ENTRY_REGS(e1);
         v4u wa[TRIPS], wb[TRIPS];
         const int pl = p1 - 1;
-#define SPMV_TILE_PASS(cur, fill, wcur, wnext, P)                                                                       \
-    tile_pass<T, NT, CH, TRIPS, PACK>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), wnext, P, pl, pass_desc,    \
-                                stage_ok, probe, acc, xs, wave_r, wave_h, tcol, tkey, tval, x)
+#define SPMV_TILE_PASS(cur, fill, wcur, D, DW, DE, P)                                                             \
+    tile_pass<T, NT, CH, TRIPS, PACK>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), D, DW, DE, (P) <= pl, \
+                                      stage_ok, probe, acc, xs, wave_r, wave_h, tcol, tkey, tval, x)
         SPMV_TILE_ENTRY_REGS(e2);
         SPMV_TILE_ENTRY_REGS(e3);
-        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e0), pass_desc[p0], tcol, tkey, tval);
-        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e1), pass_desc[min(p0 + 1, pl)], tcol, tkey, tval);
-        tile_issue_window<T, TRIPS>(wa, pass_desc[p0], stage_ok, x);
-        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e2), pass_desc[min(p0 + 2, pl)], tcol, tkey, tval);
-        for (int p = p0; p < p1; p += 4) {  // wave-uniform
-            SPMV_TILE_PASS(e0, e3, wa, wb, p);
-            if (p + 1 < p1) SPMV_TILE_PASS(e1, e0, wb, wa, p + 1);
-            if (p + 2 < p1) SPMV_TILE_PASS(e2, e1, wa, wb, p + 2);
-            if (p + 3 < p1) SPMV_TILE_PASS(e3, e2, wb, wa, p + 3);
+        // descriptors of passes p .. p + 3 (clamped to the block's last pass), replaced one per pass
+        int4 d0 = pass_desc[p0], d1 = pass_desc[min(p0 + 1, pl)], d2 = pass_desc[min(p0 + 2, pl)], d3 = pass_desc[min(p0 + 3, pl)];
+        // (in the order the passes send them out: slice p, entries p + 1; slice p + 1, entries p + 2)
+        // (the fences keep the compiler from sorting them by kind: what counts is their order in the queue)
+        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e0), d0, tcol, tkey, tval);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_issue_window<T, TRIPS>(wa, d0, PACK ? 1 : stage_ok, x);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e1), d1, tcol, tkey, tval);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_issue_window<T, TRIPS>(wb, d1, PACK ? 1 : stage_ok, x);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_issue_entries<T, NT, CH, PACK>(SPMV_TILE_ENTRY_ARGS(e2), d2, tcol, tkey, tval);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PACK) {
+            // the loop always runs four passes per trip: a pass it may skip leaves the compiler's count of what is in
+            // flight different on the two paths, and every wait behind the merge is then for the larger one.  The last
+            // one to three passes follow the loop, where nothing merges back.
+            int p = p0;
+            for (; p + 4 <= p1; p += 4) {  // wave-uniform
+                const int4 n0 = pass_desc[min(p + 4, pl)];
+                SPMV_TILE_PASS(e0, e3, wa, d0, d2, d3, p);
+                const int4 n1 = pass_desc[min(p + 5, pl)];
+                SPMV_TILE_PASS(e1, e0, wb, d1, d3, n0, p + 1);
+                const int4 n2 = pass_desc[min(p + 6, pl)];
+                SPMV_TILE_PASS(e2, e1, wa, d2, n0, n1, p + 2);
+                const int4 n3 = pass_desc[min(p + 7, pl)];
+                SPMV_TILE_PASS(e3, e2, wb, d3, n1, n2, p + 3);
+                d0 = n0;
+                d1 = n1;
+                d2 = n2;
+                d3 = n3;
+            }
+            if (p < p1) {  // (what they send out repeats the last pass: d0 .. d3 are clamped to it)
+                SPMV_TILE_PASS(e0, e3, wa, d0, d2, d3, p);
+                if (p + 1 < p1) {
+                    SPMV_TILE_PASS(e1, e0, wb, d1, d3, d3, p + 1);
+                    if (p + 2 < p1) SPMV_TILE_PASS(e2, e1, wa, d2, d3, d3, p + 2);
+                }
+            }
+        } else {
+            // (plans with gather passes wait for their gathers in every pass anyway -- which drains the queue down to
+            // what went out behind them -- and with the tail passes written out these instantiations spill)
+            for (int p = p0; p < p1; p += 4) {  // wave-uniform
+                const int4 n0 = pass_desc[min(p + 4, pl)];
+                SPMV_TILE_PASS(e0, e3, wa, d0, d2, d3, p);
+                const int4 n1 = pass_desc[min(p + 5, pl)];
+                if (p + 1 < p1) SPMV_TILE_PASS(e1, e0, wb, d1, d3, n0, p + 1);
+                const int4 n2 = pass_desc[min(p + 6, pl)];
+                if (p + 2 < p1) SPMV_TILE_PASS(e2, e1, wa, d2, n0, n1, p + 2);
+                const int4 n3 = pass_desc[min(p + 7, pl)];
+                if (p + 3 < p1) SPMV_TILE_PASS(e3, e2, wb, d3, n1, n2, p + 3);
+                d0 = n0;
+                d1 = n1;
+                d2 = n2;
+                d3 = n3;
+            }
         }
 #undef SPMV_TILE_PASS
     }

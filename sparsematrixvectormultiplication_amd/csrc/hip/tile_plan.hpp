@@ -15,6 +15,9 @@
 //               ordered by (row, column) and the first entry of every row carries the head flag
 //   staging     a pass is staged (its slice of x copied to LDS) when its column range fits the window
 //               and holds at least one entry per `density` columns
+//   pack        EVERY pass is cut at the window and staged, however few entries that leaves it (the sparse tails
+//               of a band: a handful of passes per block with a few entries each), and its entries are packed:
+//               the kernel for such a plan has no gather and no key array, and sends out the same loads in every pass
 #pragma once
 #include <hip/hip_runtime.h>  // int4
 
@@ -42,7 +45,7 @@ struct TilePlan {
     std::vector<int> block_pass;     // [num_blocks + 1]
     std::vector<int4> pass_desc;     // {first entry, entries, window base, window columns (0 = gather)}
     std::vector<int> tcol;           // [padded entries + kTileChunkMax]
-    std::vector<unsigned short> tkey;
+    std::vector<unsigned short> tkey;  // (a packed plan: padding only)
     std::vector<T> tval;
     std::vector<unsigned char> split;  // [M] 1: row is not in the tiles (longer than lmax)
 };
@@ -58,6 +61,7 @@ struct Part {  // what one builder thread produced for its range of blocks
     std::vector<T> tval;
     long long entries = 0, staged_entries = 0, staged_cols = 0;
     int max_win = 0;
+    bool failed = false;
 };
 
 // std::sort of 64-bit keys whose top 32 bits are < key_top, with several threads: bucket by the leading bits
@@ -108,7 +112,16 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
         const size_t n = keyed.size();
         // one pass in CSR order when everything fits: no sort needed to cut, (row, column) is the input order
         bool sorted_by_col = false;
-        if (n > (size_t)chunk) {
+        bool one_pass = n <= (size_t)chunk;
+        if (one_pass && pack && n > 0) {  // ... and, in a plan that stages every pass, fits one window
+            uint32_t cmin = 0xffffffffu, cmax = 0;
+            for (uint64_t k : keyed) {
+                cmin = std::min(cmin, (uint32_t)(k >> 32));
+                cmax = std::max(cmax, (uint32_t)(k >> 32));
+            }
+            one_pass = (long long)cmax - (long long)(cmin & ~3u) < win_cols;
+        }
+        if (!one_pass) {
             sort_keys(keyed, col_top, inner_threads);
             sorted_by_col = true;
         }
@@ -125,8 +138,8 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
                 const size_t cap = std::min(n, i + (size_t)chunk);
                 while (w < cap && (long long)(keyed[w] >> 32) < base + win_cols) ++w;
                 const long long span = (long long)(keyed[w - 1] >> 32) - base + 1;
-                if ((long long)(w - i) * density >= span) j = w;   // dense enough: a staged pass
-                else j = cap;                                      // sparse here: a full gather pass
+                if (pack || (long long)(w - i) * density >= span) j = w;  // dense enough (pack: always): a staged pass
+                else j = cap;                                             // sparse here: a full gather pass
             }
             pass.assign(keyed.begin() + (long)i, keyed.begin() + (long)j);
             int cmin = 0x7fffffff, cmax = 0;
@@ -146,7 +159,11 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
             const int wbase = cmin & ~3;
             int wlen = ((cmax - wbase + 1) + 3) & ~3;
             wlen = std::min(wlen, ((int)col_top - wbase + kPer - 1) / kPer * kPer);
-            const bool staged = wlen <= win_cols && wlen <= (int)kTilePackColMask + 1 && (long long)count * density >= wlen;
+            const bool staged = wlen <= win_cols && wlen <= (int)kTilePackColMask + 1 && (pack || (long long)count * density >= wlen);
+            if (pack && !staged) {  // (cannot happen: every cut above is window-limited)
+                out.failed = true;
+                return;
+            }
             const int e_first = (int)out.tcol.size();
             int prev_row = -1;
             for (uint64_t k : pass) {
@@ -158,13 +175,13 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
                 else
                     out.tcol.push_back(col[e]);
                 out.tval.push_back(val[e]);
-                out.tkey.push_back((unsigned short)(lrow | (head ? kTileHead : 0)));
+                if (!pack) out.tkey.push_back((unsigned short)(lrow | (head ? kTileHead : 0)));
                 prev_row = lrow;
             }
             while (out.tcol.size() & 3) {  // the next pass starts on a multiple of 4
                 out.tcol.push_back(wbase);
                 out.tval.push_back(T(0));
-                out.tkey.push_back(0);
+                if (!pack) out.tkey.push_back(0);
             }
             out.pass_desc.push_back(int4{e_first, count, wbase, staged ? (wlen | (pack ? kTilePassPacked : 0)) : 0});
             out.entries += count;
@@ -242,13 +259,15 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
         });
     for (auto &th : pool) th.join();
     size_t total_entries = 0, total_passes = 0;
+    for (const auto &p : parts)
+        if (p.failed) return false;
     for (const auto &p : parts) {
         total_entries += p.tcol.size();
         total_passes += p.pass_desc.size();
     }
     if (total_entries + kTileChunkMax >= 0x7fffffffull) return false;
     plan.tcol.reserve(total_entries + kTileChunkMax);
-    plan.tkey.reserve(total_entries + kTileChunkMax);
+    if (!pack) plan.tkey.reserve(total_entries + kTileChunkMax);
     plan.tval.reserve(total_entries + kTileChunkMax);
     plan.pass_desc.reserve(total_passes);
     plan.block_pass.assign(1, 0);

@@ -263,13 +263,13 @@ def csr_tile_plan_check(M, N, row_ptr, col_idx, value_bytes=8, rows_per_block=20
     """Host-only self-check of the csr_tile plan (spmv_hip_csr_tile_plan_check); returns its stats."""
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
     col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
-    stats = np.zeros(6, dtype=np.int64)
+    stats = np.zeros(12, dtype=np.int64)  # the plan with gather passes, then the packed one (every pass staged)
     if nat.lib().spmv_hip_csr_tile_plan_check(int(M), int(N), _ip(row_ptr), _ip(col_idx), int(value_bytes),
                                               int(rows_per_block), int(lmax), int(density), int(chunk),
                                               int(bool(balance)), stats.ctypes.data_as(C.POINTER(C.c_longlong))) != 0:
         raise ValueError(nat.lib().spmv_hip_last_error().decode())
-    return dict(zip(("blocks", "passes", "entries", "staged_entries", "split_rows", "max_window"),
-                    (int(v) for v in stats)))
+    names = ("blocks", "passes", "entries", "staged_entries", "split_rows", "max_window")
+    return dict(zip(names + tuple("packed_" + n for n in names), (int(v) for v in stats)))
 
 
 def hll_plan_check(hll: "HllHost"):
