@@ -152,11 +152,12 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     const int chunk = 2048;
     int rb = g_tile_rows;
     const int density = g_tile_density;
-    // Which kernel: a plan most of whose entries sit in passes dense enough to stage (>= 90 % on the sample) is built
-    // PACKED -- every pass cut at the window and staged, the sparse tails too (tile_plan.hpp) -- for the kernel
-    // instantiation without gather code; anything else keeps gather passes.
+    // Which kernel: a banded matrix is built PACKED -- every pass cut at the window and staged, the sparse tails too
+    // (tile_plan.hpp) -- for the kernel instantiation without gather code, unless that leaves passes of a few entries
+    // each (entries far from the band: one window, i.e. one pass, per stray entry); anything else keeps gather passes.
     const int banded_rows = 32768 / (int)sizeof(T);
     bool want_pack = g_tile_pack != 0;
+    auto pack_pays = [&](const TilePlan<T> &p) { return p.entries >= (long long)p.pass_desc.size() * (chunk / 8); };
     {
         // a slice of the matrix from its middle (rows keep their global columns)
         const int srows = rb ? rb : banded_rows;
@@ -165,7 +166,6 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         const bool ok = tile_build<T>(sample, N, row_begin + s0, row_len + s0, hcol, hval, srows, g_tile_lmax, density,
                                       chunk, g_tile_balance != 0, 17, probe, false);
         const bool banded = ok && probe.staged_entries * 2 >= probe.entries;
-        want_pack = want_pack && ok && probe.staged_entries * 10 >= probe.entries * 9;
         if (!rb) {
             if (banded) {
                 rb = banded_rows;
@@ -175,13 +175,18 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
                 tb.scattered = true;
             }
         }
+        want_pack = want_pack && banded;
+        if (want_pack) {  // the same slice as a packed plan
+            const bool pok = tile_build<T>(sample, N, row_begin + s0, row_len + s0, hcol, hval, srows, g_tile_lmax, density,
+                                           chunk, g_tile_balance != 0, 17, probe, true);
+            want_pack = pok && pack_pays(probe);
+        }
     }
     tb.packed = want_pack && !tb.scattered;
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
                                   g_tile_balance != 0, 17, tb.tiles, tb.packed);
-    // (outliers far from the band can leave a packed plan with passes of a few entries each: if they get out of
-    // hand -- fewer than chunk / 8 entries per pass on average -- the plan with gather passes is the better one)
-    if (tb.have_tiles && tb.packed && tb.tiles.entries < (long long)tb.tiles.pass_desc.size() * (chunk / 8)) {
+    // (the whole matrix may differ from the sample)
+    if (tb.have_tiles && tb.packed && !pack_pays(tb.tiles)) {
         tb.packed = false;
         tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
                                       g_tile_balance != 0, 17, tb.tiles, false);

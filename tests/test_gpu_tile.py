@@ -107,6 +107,53 @@ def test_tile_kernel_staged_passes_banded_columns(gpu, oracle, dtype, mean, sigm
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("far,N", [(0.0, 60_000), (0.004, 60_000), (0.3, 3_000_000)])
+def test_tile_kernel_packed_plan_outliers_and_fallback(gpu, oracle, dtype, far, N):
+    """Upload's choice between the two kinds of plan.  A band (with a few entries anywhere in a matrix of modest
+    width) gets the PACKED plan -- every pass cut at the window and staged, the kernel instantiation without gather
+    code -- which shows as staged entries == entries; with a third of the entries anywhere in a wide matrix every
+    stray entry would cost a window of its own, and the plan keeps gather passes.  Both against the oracle, x at
+    every alignment the staging loads can meet."""
+    rng = np.random.default_rng(int(far * 1000) + 5)
+    M = 60_000
+    rp, col, val = scattered(rng, M, N, 9, sigma=2500, dtype=dtype)
+    stray = rng.random(rp[-1]) < far
+    col = col.copy()
+    col[stray] = rng.integers(0, N, int(stray.sum()))
+    rows = np.repeat(np.arange(M), np.diff(rp))
+    order = np.lexsort((col, rows))
+    col, val = col[order], val[order]
+    x = rng.uniform(-1, 1, N).astype(dtype)
+    y_ref = reference(oracle, rp, col, val, x, dtype)
+    item = np.dtype(dtype).itemsize
+    L = sp.lib()
+    with tuned(stream_tile=1, tile_rows=2048):
+        with sp.CsrDevice(M, N, rp, col, val) as dev:
+            info = dev.info()
+            assert info["stream_kernel"] == 3 and info["tile_entries"] == rp[-1]
+            packed = info["tile_staged_entries"] == info["tile_entries"]
+            assert packed == (far < 0.1), info
+            if packed:
+                assert info["tile_staged_cols"] > 0
+            check(dev, x, y_ref, rp, col, val, dtype, f"packed={packed} far={far}")
+            buf, ybuf = C.c_void_p(), C.c_void_p()
+            assert L.spmv_hip_malloc(C.byref(buf), (N + 64) * item) == 0 and L.spmv_hip_malloc(C.byref(ybuf), M * item) == 0
+            try:
+                for shift in (item, 3 * item, 16):
+                    xp = C.c_void_p(buf.value + shift)
+                    assert L.spmv_hip_memcpy_h2d(xp, x.ctypes.data_as(C.c_void_p), N * item) == 0
+                    assert L.spmv_hip_memset(ybuf, 0xFF, M * item) == 0
+                    assert L.spmv_hip_csr_run_on(dev.h, sp.CSR_STREAM, xp, ybuf, None) == 0
+                    y = np.empty(M, dtype=dtype)
+                    assert L.spmv_hip_memcpy_d2h(y.ctypes.data_as(C.c_void_p), ybuf, M * item) == 0
+                    err = np.max(np.abs(y.astype(np.float64) - y_ref)) / np.max(np.abs(y_ref))
+                    assert err <= (1e-10 if dtype == np.float64 else FP32_NORMWISE_RTOL), f"shift={shift}: {err:.3e}"
+            finally:
+                L.spmv_hip_free(buf)
+                L.spmv_hip_free(ybuf)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_tile_kernel_skewed_rows_sub_runs_and_split_rows(gpu, oracle, dtype):
     """Power-law row lengths: runs longer than one lane's share (sub-runs + multi heads), rows beyond the tile
     limit (split-row kernels, pieces cut at column stripes), empty rows, a last block that is not full."""
