@@ -128,7 +128,10 @@ int spmv_hip_flush_cache(size_t bytes);
  *                     ones) | a multiple of 256 in 256..16384 rows per block; "tile_lmax" (1024) longest row kept in
  *                     the ordinary tiles; "tile_density" (16) columns per entry up to which a pass is staged in LDS;
  *                     "tile_balance" 1 | 0 row blocks of equal entry / row counts; "tile_long" 1 | 0 | 2 a tile plan of
- *                     their own for the rows beyond tile_lmax (0: split-row kernels, 2: however few they are)
+ *                     their own for the rows beyond tile_lmax (0: split-row kernels, 2: however few they are);
+ *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 40 KiB window and
+ *                     staged, keys in the column words, kernel instantiation without gather code) unless its passes
+ *                     would average fewer than 256 entries; 0: always the plan with gather passes
  *   read at launch
  *     "stream_kind"   -1 (auto: x-window kernel when the handle has a plan, csr_tile when it has tiles, else
  *                     csr_stream) | 5 x-window | 6 csr_tile |

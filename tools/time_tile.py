@@ -81,7 +81,7 @@ for name in want:
                 for probe in [int(v) for v in os.environ.get("TILE_PROBE", "").split(",") if v]:  # EXPERIMENTAL=1 builds only
                     set_tuning("tile_probe", probe)
                     pm = dev.time(sp.CSR_STREAM, 2, 10, zero_y=False)
-                    print(f"      probe {probe} (1 no staging, 2 no gathers, 4 no run sums): {pm.mean() * 1e3:8.1f} us", flush=True)
+                    print(f"      probe {probe} (1 loads, staging, barriers only; 2 no gathers; 4 no run sums; 8 one workgroup per CU): {pm.mean() * 1e3:8.1f} us", flush=True)
                     set_tuning("tile_probe", 0)
                 print(f"   tile pack={dn_pack} rows={tr:5d} density={dn:3d}: {ms.mean() * 1e3:8.1f} us  {info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  "
                       f"{info['algo_bytes'] / ms.mean() / 1e6 / 80:5.1f} %  blocks={info['tile_blocks']} passes={info['tile_passes']} "
