@@ -37,7 +37,7 @@ class tuned:
 
     def __exit__(self, *exc):
         defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 16, "stream_kind": -1,
-                    "tile_balance": 1, "tile_long": 1, "tile_pack": 1}
+                    "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 
@@ -291,3 +291,44 @@ def test_tile_kernel_inside_a_graph_replay_and_power_iteration(gpu, oracle):
                 lam_ref = float(np.linalg.norm(ys))
                 xs = ys / lam_ref
             assert abs(lam - lam_ref) <= 1e-10 * lam_ref
+
+
+def test_tile_kernel_random_shapes(gpu, oracle):
+    """Seeded sweep over shapes the fixed cases do not hit: rows per block above and below M, N that is not a
+    multiple of 4 (the last window piece ends inside a 16-byte piece), bands at the matrix edges, stray entries,
+    empty rows, rows longer than a pass, both kinds of plan, fp64 and fp32 -- every case against the oracle, with y
+    poisoned first and the launch repeated (bit-reproducible)."""
+    rng = np.random.default_rng(20260)
+    packed_seen = plain_seen = 0
+    for case in range(48):
+        dtype = np.float64 if case % 3 else np.float32
+        M = int(rng.integers(1, 30_000))
+        N = int(rng.integers(1, 200_000)) if case % 4 else M
+        mean = float(rng.choice([0.5, 2, 3, 9, 30, 120]))
+        if M * mean > 600_000:
+            mean = 600_000 / M
+        sigma = None if case % 5 == 0 else float(rng.choice([5, 300, 3000, 40_000]))
+        rp, col, val = scattered(rng, M, N, mean, sigma=sigma, dtype=dtype)
+        if rp[-1] and case % 7 == 3:  # a few stray entries anywhere
+            stray = rng.random(rp[-1]) < 0.01
+            col = col.copy()
+            col[stray] = rng.integers(0, N, int(stray.sum()))
+            rows = np.repeat(np.arange(M), np.diff(rp))
+            order = np.lexsort((col, rows))
+            col, val = col[order], val[order]
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        y_ref = reference(oracle, rp, col, val, x, dtype)
+        rows_per_block = int(rng.choice([256, 512, 2048, 4096]))
+        with tuned(stream_tile=1, stream_local=0, tile_rows=rows_per_block, tile_pack=int(case % 6 != 5),
+                   tile_lmax=int(rng.choice([64, 1024]))):
+            with sp.CsrDevice(M, N, rp, col, val) as dev:
+                info = dev.info()
+                if info["stream_kernel"] != 3:
+                    continue  # (an empty matrix gets no plan)
+                if info["tile_entries"] and info["tile_staged_entries"] == info["tile_entries"]:
+                    packed_seen += 1
+                else:
+                    plain_seen += 1
+                check(dev, x, y_ref, rp, col, val, dtype,
+                      f"case {case}: M={M} N={N} mean={mean} sigma={sigma} rows={rows_per_block} {np.dtype(dtype).name}")
+    assert packed_seen >= 8 and plain_seen >= 8, (packed_seen, plain_seen)
