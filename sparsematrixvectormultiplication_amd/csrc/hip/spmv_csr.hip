@@ -157,7 +157,12 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     // each (entries far from the band: one window, i.e. one pass, per stray entry); anything else keeps gather passes.
     const int banded_rows = 32768 / (int)sizeof(T);
     bool want_pack = g_tile_pack != 0;
-    auto pack_pays = [&](const TilePlan<T> &p) { return p.entries >= (long long)p.pass_desc.size() * (chunk / 8); };
+    // (... or slices several times the size of the entries they serve: 40 KiB of x out of L2 for a few hundred entries
+    // costs as much as gathering them, measured on 30 uniformly random columns per row of a 1 M-column matrix)
+    auto pack_pays = [&](const TilePlan<T> &p) {
+        return p.entries >= (long long)p.pass_desc.size() * (chunk / 8) &&
+               p.staged_cols * (long long)sizeof(T) <= 2 * p.entries * (long long)(4 + sizeof(T));
+    };
     {
         // a slice of the matrix from its middle (rows keep their global columns)
         const int srows = rb ? rb : banded_rows;
@@ -183,11 +188,20 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.packed = want_pack && !tb.scattered;
+    // (auto) plans with gather passes pay once x has outgrown the L2s: with 8.7 MB of x (1.09 M fp64 columns; the
+    // reference's roadNet-PA / webbase-1M sizes) the gather kernels are 10-25 % faster (44 vs 55 us at 3 uniformly random
+    // columns per row, 123 vs 136 at 10, 95 vs 102 us power-law fp32), with 16 MB the tiles are (70 vs 94, 168 vs 292 us);
+    // a packed plan wins at that size as well (road-like 1.09 M rows: 24 vs 29 us)
+    if (g_stream_tile < 0 && !tb.packed && (long long)N * (long long)sizeof(T) < (12LL << 20)) return;
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
                                   g_tile_balance != 0, 17, tb.tiles, tb.packed);
     // (the whole matrix may differ from the sample)
     if (tb.have_tiles && tb.packed && !pack_pays(tb.tiles)) {
         tb.packed = false;
+        if (g_stream_tile < 0 && (long long)N * (long long)sizeof(T) < (12LL << 20)) {
+            tb.have_tiles = false;
+            return;
+        }
         tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
                                       g_tile_balance != 0, 17, tb.tiles, false);
     }

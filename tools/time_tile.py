@@ -40,8 +40,21 @@ CASES = {
     "band": lambda: banded_random(2_000_000, 30, 20000.0),
     "uniform": lambda: uniform_random(4_000_000, 20),
     "powerlaw": lambda: synth.powerlaw(1 << 24, 1 << 20, 5),
+    # the sizes of the reference's own graph matrices (roadNet-PA, webbase-1M: ~1 M rows, ~3 M entries; they fit the
+    # Infinity Cache): does the auto rule (csr_tile from 2^20 rows on) still pay there?
+    "road1m": lambda: banded_random(1_090_000, 3, 2000.0),
+    "uniform1m": lambda: uniform_random(1_090_000, 3),
+    "web1m": lambda: synth.powerlaw(1 << 20, 1 << 12, 7),
 }
-want = sys.argv[1:] or list(CASES)
+want = sys.argv[1:] or ["road", "band", "uniform", "powerlaw"]
+for w in want:  # uniform:<rows>:<per row>, band:<rows>:<per row>:<sigma>, web:<log2 rows>:<longest row>
+    f = w.split(":")
+    if len(f) > 1 and f[0] == "uniform":
+        CASES[w] = lambda f=f: uniform_random(int(f[1]), int(f[2]))
+    elif len(f) > 1 and f[0] == "band":
+        CASES[w] = lambda f=f: banded_random(int(f[1]), int(f[2]), float(f[3]))
+    elif len(f) > 1 and f[0] == "web":
+        CASES[w] = lambda f=f: synth.powerlaw(1 << int(f[1]), int(f[2]), 7)
 tile_rows = [int(v) for v in os.environ.get("TILE_ROWS", "2048").split(",")]
 dens = [int(v) for v in os.environ.get("TILE_DENSITY", "16").split(",")]
 chunks = [2048]
