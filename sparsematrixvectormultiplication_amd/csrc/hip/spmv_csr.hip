@@ -146,6 +146,8 @@ struct TileBuild {
 //    too many of them are on the way at once: the tallest blocks (up to 16384 rows) that still leave ~2 per CU, ONE
 //    workgroup per CU.  Power-law matrix (fp32, 2^24 rows): 2.90 ms at 8192 rows, 1.97 ms at 16384 with one
 //    workgroup per CU, 2.39 ms with two.
+constexpr int kTileGatherMinCols = 1536 * 1024;  // (auto) columns from which a tile plan with gather passes is built
+
 template <typename T>
 void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, const int *rp, long long nz, const int *hcol,
                    const T *hval, TileBuild<T> &tb) {
@@ -188,17 +190,18 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.packed = want_pack && !tb.scattered;
-    // (auto) plans with gather passes pay once x has outgrown the L2s: with 8.7 MB of x (1.09 M fp64 columns; the
+    // (auto) plans with gather passes pay once x has outgrown the L2s -- from 1.5 M columns on: with 8.7 MB of x (1.09 M fp64 columns; the
     // reference's roadNet-PA / webbase-1M sizes) the gather kernels are 10-25 % faster (44 vs 55 us at 3 uniformly random
     // columns per row, 123 vs 136 at 10, 95 vs 102 us power-law fp32), with 16 MB the tiles are (70 vs 94, 168 vs 292 us);
     // a packed plan wins at that size as well (road-like 1.09 M rows: 24 vs 29 us)
-    if (g_stream_tile < 0 && !tb.packed && (long long)N * (long long)sizeof(T) < (12LL << 20)) return;
+    // (in columns rather than bytes: fp32 power-law with 2^21 columns = 8.4 MB of x is 23 % faster in tiles)
+    if (g_stream_tile < 0 && !tb.packed && N < kTileGatherMinCols) return;
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
                                   g_tile_balance != 0, 17, tb.tiles, tb.packed);
     // (the whole matrix may differ from the sample)
     if (tb.have_tiles && tb.packed && !pack_pays(tb.tiles)) {
         tb.packed = false;
-        if (g_stream_tile < 0 && (long long)N * (long long)sizeof(T) < (12LL << 20)) {
+        if (g_stream_tile < 0 && N < kTileGatherMinCols) {
             tb.have_tiles = false;
             return;
         }
