@@ -123,12 +123,16 @@ int spmv_hip_flush_cache(size_t bytes);
  *                     line limit), else / otherwise on the host
  *     "local_cap"     0 (auto = 2048) | 1024 | 2048 | 3072   stage of the x-window kernels (3072: +0.5..3 % on the
  *                     nlpkkt-like matrix depending on the box, -8 % on the cant-like one)
+ *     "skew_rows"     1 | 0   handles that run the gather kernels give rows longer than max(128, 16 x the average
+ *                     row) to the split-row kernels (one workgroup per row piece) instead of leaving each to one lane
  *     "stream_tile"   -1 (auto) | 0 | 1   build the 2-D tile plan (csr_tile) when the matrix gets no x-window plan;
  *                     "tile_rows" 0 (auto: 32 KiB of accumulators for banded matrices, up to 16384 rows for scattered
  *                     ones) | a multiple of 256 in 256..16384 rows per block; "tile_lmax" (1024) longest row kept in
  *                     the ordinary tiles; "tile_density" (16) columns per entry up to which a pass is staged in LDS;
  *                     "tile_balance" 1 | 0 row blocks of equal entry / row counts; "tile_long" 1 | 0 | 2 a tile plan of
  *                     their own for the rows beyond tile_lmax (0: split-row kernels, 2: however few they are);
+ *                     "tile_fit" 1 | 0 (with tile_rows 0) the number of row blocks is fitted to whole rounds of the
+ *                     workgroups the chip holds at once (512 banded / 256 scattered), blocks up to the tallest the LDS takes;
  *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 40 KiB window and
  *                     staged, keys in the column words, kernel instantiation without gather code) unless its passes
  *                     would average fewer than 256 entries; 0: always the plan with gather passes

@@ -158,6 +158,12 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     // (tile_plan.hpp) -- for the kernel instantiation without gather code, unless that leaves passes of a few entries
     // each (entries far from the band: one window, i.e. one pass, per stray entry); anything else keeps gather passes.
     const int banded_rows = 32768 / (int)sizeof(T);
+    // the tallest blocks a CU's 160 KiB of LDS take: two workgroups (banded) / one (scattered), each with its wave
+    // slots, its accumulators and a full 40 KiB x slice
+    constexpr int kSliceBytes = kTileTrips * kTileTripBytes;
+    constexpr int banded_rows_max = (160 * 1024 / 2 - kTileSlotBytes - kSliceBytes) / (int)sizeof(T) / 256 * 256;
+    constexpr int scattered_rows_max =
+        std::min(kTileRowsMax, (160 * 1024 - kTileSlotBytes - kSliceBytes) / (int)sizeof(T) / 256 * 256);
     bool want_pack = g_tile_pack != 0;
     // (... or slices several times the size of the entries they serve: 40 KiB of x out of L2 for a few hundred entries
     // costs as much as gathering them, measured on 30 uniformly random columns per row of a 1 M-column matrix)
@@ -179,6 +185,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
             } else {
                 rb = 16384;
                 while (rb > 2048 && (long long)Ml < 448LL * rb) rb >>= 1;  // at least ~1.75 blocks per CU
+                rb = std::min(rb, scattered_rows_max);
                 tb.scattered = true;
             }
         }
@@ -196,8 +203,34 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     // a packed plan wins at that size as well (road-like 1.09 M rows: 24 vs 29 us)
     // (in columns rather than bytes: fp32 power-law with 2^21 columns = 8.4 MB of x is 23 % faster in tiles)
     if (g_stream_tile < 0 && !tb.packed && N < kTileGatherMinCols) return;
+    // How many blocks: equal-work blocks finish together, so the kernel runs in ROUNDS of as many blocks as the chip
+    // holds at once (2 per CU banded, 1 scattered) and a last round of a few blocks costs a whole one -- 530 blocks on
+    // 512 places took 2 x 215 us on a dense band, 1040 on 256 five rounds instead of four on the power-law matrix.
+    // So (auto): the smallest number of rounds k for which blocks of up to the tallest height the LDS takes, closed
+    // at in_tiles / (98.5 % of k rounds' places) entries, come out as at most k rounds' worth.
+    long long target = 0;
+    if (!g_tile_rows && g_tile_balance && g_tile_fit) {
+        const int places = (tb.scattered ? 1 : 2) * g_num_cus;
+        const int rows_max = tb.scattered ? scattered_rows_max : banded_rows_max;
+        long long in_tiles = 0;
+        for (int r = 0; r < Ml; ++r)
+            if (row_len[r] <= g_tile_lmax) in_tiles += row_len[r];
+        const long long full = std::max(1, (Ml + rb - 1) / rb);
+        const int b0 = (int)tile_cut_rows(Ml, row_len, g_tile_lmax, rb, std::max<long long>(chunk, (in_tiles + full - 1) / full)).size() - 1;
+        const int kmax = (b0 + places - 1) / places;
+        for (int k = 1; k <= kmax; ++k) {
+            const long long want = (long long)k * places * 197 / 200;
+            const long long t = std::max<long long>(chunk, (in_tiles + want - 1) / want);
+            const int b = (int)tile_cut_rows(Ml, row_len, g_tile_lmax, rows_max, t).size() - 1;
+            if (b <= k * places) {
+                rb = rows_max;
+                target = t;
+                break;
+            }
+        }
+    }
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
-                                  g_tile_balance != 0, 17, tb.tiles, tb.packed);
+                                  g_tile_balance != 0, 17, tb.tiles, tb.packed, target);
     // (the whole matrix may differ from the sample)
     if (tb.have_tiles && tb.packed && !pack_pays(tb.tiles)) {
         tb.packed = false;
@@ -206,7 +239,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
             return;
         }
         tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
-                                      g_tile_balance != 0, 17, tb.tiles, false);
+                                      g_tile_balance != 0, 17, tb.tiles, false, target);
     }
     // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
     if (tb.have_tiles && g_stream_tile < 0 && !g_tile_long && tb.tiles.entries * 2 < nz) tb.have_tiles = false;
@@ -604,8 +637,25 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     m->ring_ok = m->stream_cap == kRingCap && Ml > 0 && (double)nz / Ml >= 1.25 * kRingCap / (kRingRows - 1);
     if (m->ring_ok) rows_cap = kRingRows - 1;
 #endif
+    // Skewed rows (gather kernels): a block's rows are summed by lane groups sized for the NUMBER of rows in it, so in
+    // a block of a few hundred short rows one row of a thousand entries is summed by a single lane while everybody else
+    // waits (webbase-like stand-in, 1 M rows, 3.3 entries per row on average, 2 262 in the longest: 73 us; with its rows
+    // beyond the limit below handed to the split-row kernels, one workgroup each: see profiles/r2_reference_list_stand_ins.md).
+    // Rows longer than max(128, 16 x the average row) count as long there -- from 2^20 entries on: the two extra
+    // launches of the split-row kernels cost ~5 us, more than a small matrix's whole product.
+    std::vector<unsigned char> skew_split;
+    if (!have_local && g_skew_rows && Ml > 0 && nz >= (1LL << 20)) {
+        const long long limit = std::max<long long>(128, 16 * (nz / Ml));
+        if (limit < m->stream_cap - 3) {
+            bool any = false;
+            skew_split.assign((size_t)Ml, 0);
+            for (int r = 0; r < Ml; ++r)
+                if (rp[(size_t)r + 1] - rp[(size_t)r] > limit) skew_split[(size_t)r] = 1, any = true;
+            if (!any) skew_split.clear();
+        }
+    }
     csr_build_blocks(Ml, rp.data(), m->stream_cap, rows_cap, desc, pieces, long_rows,
-                     have_local ? &local.split : nullptr);
+                     have_local ? &local.split : skew_split.empty() ? nullptr : &skew_split);
     m->num_blocks = (int)desc.size();
     m->num_long = (int)long_rows.size();
     m->num_partial = (int)pieces.size();

@@ -199,10 +199,29 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
 
 }  // namespace tile_detail
 
-// false: the tiles would not hold the matrix (entry offsets beyond 32 bits)
+// Row blocks: consecutive rows, at most rows_per_block of them, closed once they hold `target` entries (rows longer than
+// lmax hold none: they are not in the tiles).  Returns the first row of every block and M behind the last.
+inline std::vector<int> tile_cut_rows(int M, const int *row_len, int lmax, int rows_per_block, long long target) {
+    std::vector<int> block_row(1, 0);
+    long long held = 0;
+    for (int r = 0; r < M; ++r) {
+        const int len = row_len[r] > lmax ? 0 : row_len[r];
+        if (r - block_row.back() == rows_per_block || (held >= target && r > block_row.back())) {
+            block_row.push_back(r);
+            held = 0;
+        }
+        held += len;
+    }
+    if (M > 0) block_row.push_back(M);
+    return block_row;
+}
+
+// false: the tiles would not hold the matrix (entry offsets beyond 32 bits).  target_entries: entries at which a block
+// closes (0: balance ? the mean of a full-height block : never -- blocks of rows_per_block rows)
 template <typename T>
 bool tile_build(int M, int N, const int *row_begin, const int *row_len, const int *col, const T *val, int rows_per_block,
-                int lmax, int density, int chunk, bool balance, int pos_bits, TilePlan<T> &plan, bool pack = true) {
+                int lmax, int density, int chunk, bool balance, int pos_bits, TilePlan<T> &plan, bool pack = true,
+                long long target_entries = 0) {
     // the window a pass may stage: kTileTrips trips of the workgroup = 40 KiB, which with a 2048-entry chunk and
     // 2048 fp64 accumulators lets two workgroups share a CU's LDS, and with 8192 of them still fits one
     const int win_cols = kTileTrips * kTileTripBytes / (int)sizeof(T);
@@ -218,20 +237,10 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
     }
     // block boundaries: the row cap, and (balance) the mean entry count of a full-height block
     const long long full_blocks = std::max(1, (M + rows_per_block - 1) / rows_per_block);
-    const long long target = balance ? std::max<long long>(chunk, (in_tiles + full_blocks - 1) / full_blocks) : (1LL << 62);
-    plan.block_row.assign(1, 0);
-    {
-        long long held = 0;
-        for (int r = 0; r < M; ++r) {
-            const int len = plan.split[r] ? 0 : row_len[r];
-            if (r - plan.block_row.back() == rows_per_block || (held >= target && r > plan.block_row.back())) {
-                plan.block_row.push_back(r);
-                held = 0;
-            }
-            held += len;
-        }
-        if (M > 0) plan.block_row.push_back(M);
-    }
+    const long long target = target_entries > 0 ? std::max<long long>(chunk, target_entries)
+                             : balance          ? std::max<long long>(chunk, (in_tiles + full_blocks - 1) / full_blocks)
+                                                : (1LL << 62);
+    plan.block_row = tile_cut_rows(M, row_len, lmax, rows_per_block, target);
     plan.num_blocks = (int)plan.block_row.size() - 1;
     const int B = plan.num_blocks;
     int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
