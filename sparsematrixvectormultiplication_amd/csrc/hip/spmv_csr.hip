@@ -158,12 +158,9 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     // (tile_plan.hpp) -- for the kernel instantiation without gather code, unless that leaves passes of a few entries
     // each (entries far from the band: one window, i.e. one pass, per stray entry); anything else keeps gather passes.
     const int banded_rows = 32768 / (int)sizeof(T);
-    // the tallest blocks a CU's 160 KiB of LDS take: two workgroups (banded) / one (scattered), each with its wave
-    // slots, its accumulators and a full 40 KiB x slice
-    constexpr int kSliceBytes = kTileTrips * kTileTripBytes;
-    constexpr int banded_rows_max = (160 * 1024 / 2 - kTileSlotBytes - kSliceBytes) / (int)sizeof(T) / 256 * 256;
-    constexpr int scattered_rows_max =
-        std::min(kTileRowsMax, (160 * 1024 - kTileSlotBytes - kSliceBytes) / (int)sizeof(T) / 256 * 256);
+    // the tallest blocks a CU's LDS takes (tile_kernels.hpp): the packed kernel is built for the banded limit
+    constexpr int banded_rows_max = tile_banded_rows_max<T>();
+    constexpr int scattered_rows_max = tile_scattered_rows_max<T>();
     bool want_pack = g_tile_pack != 0;
     // (... or slices several times the size of the entries they serve: 40 KiB of x out of L2 for a few hundred entries
     // costs as much as gathering them, measured on 30 uniformly random columns per row of a 1 M-column matrix)
@@ -189,7 +186,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
                 tb.scattered = true;
             }
         }
-        want_pack = want_pack && banded;
+        want_pack = want_pack && banded && rb <= banded_rows_max;
         if (want_pack) {  // the same slice as a packed plan
             const bool pok = tile_build<T>(sample, N, row_begin + s0, row_len + s0, hcol, hval, srows, g_tile_lmax, density,
                                            chunk, g_tile_balance != 0, 17, probe, true);
@@ -245,6 +242,8 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     // (auto) a matrix made mostly of rows beyond the tile limit gains nothing without the long rows' plan
     if (tb.have_tiles && g_stream_tile < 0 && !g_tile_long && tb.tiles.entries * 2 < nz) tb.have_tiles = false;
     if (!tb.have_tiles) return;
+    // one workgroup per place of the chip walks several blocks back to back (tile_streams 0: one workgroup per block)
+    tile_make_streams(tb.tiles, g_tile_streams ? (tb.scattered ? 1 : 2) * g_num_cus : 0x3fffffff);
     // The rows beyond the tile limit, compacted: their own row blocks (<= 2048 of them each), same passes -- so many
     // entries per column range that every pass is staged: the long rows' x lookups happen in LDS at the HBM streaming
     // rate instead of going through the gather path -- and a block's passes dealt out to many workgroups.
@@ -285,9 +284,12 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
     if ((tb.have_tiles || tb.have_long_tiles) && tile_allow_lds<T>()) return -1;
     if (tb.have_tiles) {
         const TilePlan<T> &tiles = tb.tiles;
-        rc |= upload_array(&m->tile_block_pass, tiles.block_pass.data(), tiles.block_pass.size(), 1);
+        // (the kernel walks STREAMS: descriptors in stream order, the passes / blocks of every stream, the blocks' rows)
+        rc |= upload_array(&m->tile_block_pass, tiles.stream_pass.data(), tiles.stream_pass.size(), 1);
         if (!rc) rc |= upload_array(&m->tile_block_row, tiles.block_row.data(), tiles.block_row.size(), 1);
-        if (!rc) rc |= upload_array(&m->tile_pass, tiles.pass_desc.data(), tiles.pass_desc.size(), 1);
+        if (!rc) rc |= upload_array(&m->tile_pass, tiles.spass.data(), tiles.spass.size(), 1);
+        if (!rc) rc |= upload_array(&m->tile_stream_block, tiles.stream_block.data(), tiles.stream_block.size(), 1);
+        if (!rc) rc |= upload_array(&m->tile_sblock_rows, tiles.sblock_rows.data(), tiles.sblock_rows.size(), 1);
         if (!rc) rc |= upload_array(&m->tcol, tiles.tcol.data(), tiles.tcol.size(), 0);
         if (!rc) rc |= upload_array(&m->tkey, tiles.tkey.data(), tiles.tkey.size(), 0);
         if (!rc) rc |= upload_array((T **)&m->tval, tiles.tval.data(), tiles.tval.size(), 0);
@@ -295,6 +297,7 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
         if (!rc && !tb.tile_pieces.empty()) rc |= upload_array(&m->tile_pieces, tb.tile_pieces.data(), tb.tile_pieces.size(), 0);
         if (!rc) {
             m->tile_blocks = tiles.num_blocks;
+            m->tile_streams = tiles.num_streams;
             m->tile_rows = tiles.rows_per_block;
             m->tile_chunk = tiles.chunk;
             m->tile_packed = tb.packed;
@@ -851,13 +854,15 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
         long long last_max_col = -1;
         for (int p = plan.block_pass[b]; p < plan.block_pass[b + 1]; ++p) {
             const int4 d = plan.pass_desc[p];
-            const int count = d.y, wbase = d.z, wlen = d.w & (kTilePassPacked - 1);
+            const int count = d.y, wbase = d.z, wlen = d.w & kTileWlenMask;
             const bool packed = (d.w & kTilePassPacked) != 0;
             if (packed && !wlen) return fail("tile_plan_check: pass %d is packed without a window", p);
             // a packed plan is for the kernel without gather code: every pass staged and packed, no key array
             if (packed != pack) return fail("tile_plan_check: pass %d of a %s plan is %s", p, pack ? "packed" : "plain", packed ? "packed" : "not");
             constexpr int kPer = 16 / (int)sizeof(T);
-            if (count <= 0 || count > chunk || (d.x & 3) || (wbase & 3) || (wlen % kPer) || wlen < 0)
+            // (a block without entries carries one pass of none)
+            const bool none = count == 0 && plan.block_pass[b + 1] - plan.block_pass[b] == 1;
+            if ((count <= 0 && !none) || count > chunk || (d.x & 3) || (wbase & 3) || (wlen % kPer) || wlen < 0)
                 return fail("tile_plan_check: pass %d is malformed", p);
             if ((size_t)d.x + (size_t)count > plan.tcol.size() - kTileChunkMax) return fail("tile_plan_check: pass %d leaves the arrays", p);
             if (wlen && (wlen > win_cols || wbase + wlen > (N + kPer - 1) / kPer * kPer))
@@ -897,6 +902,34 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
         }
     }
     if (seen_entries != plan.entries) return fail("tile_plan_check: entry count disagrees");
+    // streams (what a workgroup walks): every block exactly once, its passes in order, the flag on its last pass
+    for (int places : {8, 64, 512, 1 << 30}) {
+        tile_make_streams(plan, places);
+        if (plan.spass.size() != plan.pass_desc.size() || (int)plan.sblock_rows.size() != plan.num_blocks ||
+            (int)plan.stream_pass.size() != plan.num_streams + 1 || (int)plan.stream_block.size() != plan.num_streams + 1 ||
+            (plan.num_streams & 7) || (plan.num_blocks > places && plan.num_streams > std::max(8, places / 8 * 8)))
+            return fail("tile_plan_check: stream tables disagree (%d places)", places);
+        std::vector<unsigned char> seen_block((size_t)plan.num_blocks, 0);
+        for (int st = 0; st < plan.num_streams; ++st) {
+            int p = plan.stream_pass[(size_t)st];
+            for (int k = plan.stream_block[(size_t)st]; k < plan.stream_block[(size_t)st + 1]; ++k) {
+                const int2 br = plan.sblock_rows[(size_t)k];
+                const int b = (int)(std::upper_bound(plan.block_row.begin(), plan.block_row.end() - 1, br.x) - plan.block_row.begin()) - 1;
+                if (b < 0 || b >= plan.num_blocks || plan.block_row[(size_t)b] != br.x || plan.block_row[(size_t)b + 1] - br.x != br.y ||
+                    seen_block[(size_t)b]++)
+                    return fail("tile_plan_check: stream %d lists a block twice or with the wrong rows", st);
+                for (int q = plan.block_pass[(size_t)b]; q < plan.block_pass[(size_t)b + 1]; ++q, ++p) {
+                    const int4 a = plan.pass_desc[(size_t)q], c = plan.spass[(size_t)p];
+                    const bool last = q + 1 == plan.block_pass[(size_t)b + 1];
+                    if (a.x != c.x || a.y != c.y || a.z != c.z || (a.w | (last ? kTilePassLast : 0)) != c.w)
+                        return fail("tile_plan_check: stream %d does not repeat block %d's passes", st, b);
+                }
+            }
+            if (p != plan.stream_pass[(size_t)st + 1]) return fail("tile_plan_check: stream %d's passes and blocks disagree", st);
+        }
+        for (unsigned char c : seen_block)
+            if (c != 1) return fail("tile_plan_check: a block is in no stream");
+    }
     // rows beyond the limit: stripe-cut pieces cover each exactly once, slots row by row
     std::vector<int4> pieces, long_rows;
     const int stripe_cols = (1 << 20) / (int)sizeof(T);
@@ -1042,6 +1075,8 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->tile_block_pass);
     (void)hipFree(m->tile_block_row);
     (void)hipFree(m->tile_pass);
+    (void)hipFree(m->tile_stream_block);
+    (void)hipFree(m->tile_sblock_rows);
     (void)hipFree(m->tcol);
     (void)hipFree(m->tkey);
     (void)hipFree(m->tval);
@@ -1195,9 +1230,10 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     const int which = tnt ? 1 : 0;
                     // (more than 64 KiB of dynamic LDS: allowed for these kernels once, at upload -- tile_allow_lds)
 #define SPMV_TILE(NT, PACK)                                                                                            \
-    hipLaunchKernelGGL((csr_tile<T, NT, 2048, kTileTrips, PACK>), dim3((m->tile_blocks + 7) / 8 * 8), dim3(kTileBlock), lds, s, \
-                       m->tile_blocks, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,        \
-                       m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval, x, y)
+    hipLaunchKernelGGL((csr_tile<T, NT, 2048, kTileTrips, PACK>), dim3((m->tile_streams + 7) / 8 * 8), dim3(kTileBlock), lds, s, \
+                       m->tile_streams, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,       \
+                       m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval,        \
+                       m->tile_stream_block, m->tile_sblock_rows, x, y)
                     if (m->tile_packed) { if (which) SPMV_TILE(true, true); else SPMV_TILE(false, true); }
                     else { if (which) SPMV_TILE(true, false); else SPMV_TILE(false, false); }
 #undef SPMV_TILE
@@ -1209,7 +1245,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
 #define SPMV_LTILE(NT, PACK)                                                                                           \
     hipLaunchKernelGGL((csr_tile<T, NT, 2048, kTileTrips, PACK>), dim3((L.items + 7) / 8 * 8), dim3(kTileBlock), llds, s, L.items, \
                        L.rows_per_block, stage_ok, g_tile_probe, (const int4 *)L.work, (T *)L.slab, L.block_row,        \
-                       L.block_pass, L.pass, L.tcol, L.tkey, (const T *)L.tval, x, y)
+                       L.block_pass, L.pass, L.tcol, L.tkey, (const T *)L.tval, (const int *)nullptr, (const int2 *)nullptr, x, y)
                         if (L.packed) { if (which) SPMV_LTILE(true, true); else SPMV_LTILE(false, true); }
                         else { if (which) SPMV_LTILE(true, false); else SPMV_LTILE(false, false); }
 #undef SPMV_LTILE

@@ -47,6 +47,7 @@ int g_tile_density = 16;
 int g_tile_probe = 0;
 int g_skew_rows = 1;
 int g_tile_fit = 1;
+int g_tile_streams = 1;
 int g_tile_pack = 1;
 int g_tile_long = 1;
 int g_halo_overlap = 1;
@@ -182,6 +183,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_tile_long = value;
     } else if (!strcmp(key, "tile_balance")) {
         g_tile_balance = value != 0;
+    } else if (!strcmp(key, "tile_streams")) {
+        g_tile_streams = value != 0;
     } else if (!strcmp(key, "tile_fit")) {
         g_tile_fit = value != 0;
     } else if (!strcmp(key, "skew_rows")) {

@@ -48,6 +48,7 @@ extern int g_pipe_wgs_per_cu; // resident workgroups per CU the persistent grids
 extern int g_stream_tile;     // csr_tile plan at upload: -1 = auto (no x-window plan, enough rows), 0 = never, 1 = whenever no x-window plan
 extern int g_tile_rows;       // rows per block: 0 = auto, else a power of two in 256..8192
 extern int g_tile_lmax;       // rows longer than this stay with the split-row kernels
+extern int g_tile_streams;    // 1: one csr_tile workgroup per place of the chip walks several row blocks back to back
 extern int g_tile_fit;        // 1: (auto rows) the number of row blocks is fitted to whole rounds of the chip's workgroup places
 extern int g_skew_rows;       // 1: gather-kernel handles hand rows far longer than the average to the split-row kernels
 extern int g_tile_probe;      // measurement only: bit 0 loads, staging and barriers only, bit 1 no gathers, bit 2 no run sums (y is then wrong), bit 3 one workgroup per CU
@@ -153,7 +154,10 @@ struct spmv_csr_dev {
     long long tile_entries = 0, tile_staged = 0, tile_staged_cols = 0, tile_padded = 0;
     int *tile_block_row = nullptr;    // [tile_blocks + 1] first row of every block
     int *tile_block_pass = nullptr;   // [tile_blocks + 1]
-    int4 *tile_pass = nullptr;        // [tile_passes]
+    int4 *tile_pass = nullptr;        // [tile_passes] in stream order
+    int tile_streams = 0;             // workgroups of the csr_tile launch: each walks the blocks of one stream
+    int *tile_stream_block = nullptr; // [tile_streams + 1] first block (in tile_sblock_rows) of every stream
+    int2 *tile_sblock_rows = nullptr; // [tile_blocks] {first row, rows} in stream order
     int *tcol = nullptr;              // [tile_padded + kTileChunkMax]
     unsigned short *tkey = nullptr;
     void *tval = nullptr;

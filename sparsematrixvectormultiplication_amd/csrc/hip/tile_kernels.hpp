@@ -55,6 +55,8 @@ constexpr int kTileRowMask = 0x3fff;
 // head << 31 | local row << 14 | (column - first staged column) and the key array is not read for it at all --
 // 4 + sizeof(T) bytes per entry, CSR's own, instead of 6 + sizeof(T).
 constexpr int kTilePassPacked = 1 << 30;  // pass_desc.w bit: the pass's entries are packed
+constexpr int kTilePassLast = 1 << 29;    // pass_desc.w bit (stream order only): the last pass of its block
+constexpr int kTileWlenMask = (1 << 20) - 1;  // pass_desc.w: the staged columns
 constexpr int kTilePackShift = 14;
 constexpr unsigned kTilePackColMask = (1u << kTilePackShift) - 1;
 constexpr int kTileTripBytes = kTileBlock * 16;  // x bytes one staging trip of the workgroup copies
@@ -63,6 +65,18 @@ constexpr int kTileAhead = 3;        // passes whose entries are in flight beyon
 // (a compact variant -- 24 KiB windows, 1 pass ahead, 79 VGPRs, three workgroups per CU -- was measured and is no
 // faster: road-like 191 us at 3072 rows against 173 us for this one at 4096, profiles/r2_ab_csr_tile.txt)
 constexpr int kTileSlotBytes = 256;  // LDS in front of the accumulators: one (sum, closed) slot per wavefront and quad
+constexpr int kTileLdsBytes = 160 * 1024;  // a CU's LDS
+// the tallest row blocks: two workgroups per CU (banded plans) / one (scattered), each with its wave slots, its
+// accumulators and a full 40 KiB x slice
+template <typename T>
+constexpr int tile_banded_rows_max() {
+    return (kTileLdsBytes / 2 - kTileSlotBytes - kTileTrips * kTileTripBytes) / (int)sizeof(T) / 256 * 256;
+}
+template <typename T>
+constexpr int tile_scattered_rows_max() {
+    constexpr int fit = (kTileLdsBytes - kTileSlotBytes - kTileTrips * kTileTripBytes) / (int)sizeof(T) / 256 * 256;
+    return fit < kTileRowsMax ? fit : kTileRowsMax;
+}
 
 template <typename T> struct vec4v;  // four values of a lane's quad
 template <> struct vec4v<float> { typedef float type __attribute__((ext_vector_type(4))); };
@@ -107,7 +121,7 @@ template <typename T, int TRIPS>
 __device__ __forceinline__ void tile_issue_window(v4u (&rw)[TRIPS], const int4 d, int stage_ok, const T *__restrict__ x) {
     constexpr int kPer = 16 / (int)sizeof(T);
     const int t = threadIdx.x;
-    const int wlen = stage_ok ? max(d.w & (kTilePassPacked - 1), kPer) : kPer;
+    const int wlen = stage_ok ? max(d.w & kTileWlenMask, kPer) : kPer;
     const char *src = reinterpret_cast<const char *>(x + d.z);
 #pragma unroll
     for (int k = 0; k < TRIPS; ++k) {
@@ -183,7 +197,8 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
                                           v4i (&fc)[CH / (4 * kTileBlock)], v2u (&fk)[CH / (4 * kTileBlock)],
                                           typename vec4v<T>::type (&fv)[CH / (4 * kTileBlock)],
                                           const int4 d, const int4 dw, const int4 de, bool live, int stage_ok,
-                                          int probe, T *acc, T *xs, T *wave_r, int *wave_h,
+                                          int probe, int &bi, const int2 *__restrict__ sblock_rows, int rows_per_block,
+                                          T *__restrict__ y, T *acc, T *xs, T *wave_r, int *wave_h,
                                           const int *__restrict__ tcol, const unsigned short *__restrict__ tkey,
                                           const T *__restrict__ tval, const T *__restrict__ x) {
     constexpr int kQuads = CH / (4 * kTileBlock);
@@ -198,7 +213,7 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
     const int count = live ? d.y : 0, wbase = d.z;
     // PACK: a plan all of whose passes are staged and packed (tile_plan.hpp cuts every pass at the window) -- no
     // gather, no key array, and the same loads in every pass whatever it holds
-    const int wlen = PACK ? max(d.w & (kTilePassPacked - 1), kPer) : stage_ok ? (d.w & (kTilePassPacked - 1)) : 0;
+    const int wlen = PACK ? max(d.w & kTileWlenMask, kPer) : stage_ok ? (d.w & kTileWlenMask) : 0;
     if constexpr (PACK) {
         // every piece is stored, needed or not, each to its own place (the launch gives xs room for all TRIPS trips): a
         // store the compiler may skip leaves its load pending on that path, and the next write to those registers
@@ -317,6 +332,19 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
     }
     // no barrier here: the next pass stores xs (last read before the second barrier above) and rewrites the
     // wave slots only behind its own first barrier, which every lane reaches after this point
+    if (sblock_rows && live && (d.w & kTilePassLast)) {  // wave-uniform
+        // a stream's block ends here: its rows go out, the accumulators start again at 0 for the next block, whose
+        // first passes' loads are already on their way (the next accumulator update is behind the next pass's barrier)
+        // (the compiler drains the queue -- vmcnt(0) -- in front of this loop of stores: once per block, and what it
+        // waits for are the next block's first passes, which are needed next anyway; a fixed number of trips with each
+        // store under its own test instead made it spill and wait everywhere)
+        __syncthreads();
+        const int2 br = sblock_rows[bi++];
+        for (int i = t; i < rows_per_block; i += kTileBlock) {
+            if (i < br.y) y[br.x + i] = acc[i];
+            acc[i] = T(0);
+        }
+    }
 }
 
 // One workgroup per row block; passes software-pipelined: while pass p is multiplied and summed, the x slices of
@@ -333,6 +361,8 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
                                                                           const int *__restrict__ tcol,
                                                                           const unsigned short *__restrict__ tkey,
                                                                           const T *__restrict__ tval,
+                                                                          const int *__restrict__ stream_block,
+                                                                          const int2 *__restrict__ sblock_rows,
                                                                           const T *__restrict__ x, T *__restrict__ y) {
     using V4 = typename vec4v<T>::type;
     constexpr int kQuads = CH / (4 * kTileBlock);  // groups of four consecutive entries a lane holds per pass
@@ -345,27 +375,31 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
 
     // workgroup ids go round-robin over the 8 XCDs: give every XCD one contiguous eighth of the row blocks, in
     // order, so that neighbouring blocks -- whose x slices overlap -- find each other's lines in the same L2
+    // (a stream plan -- work == nullptr -- has that mapping built in: stream x + 8 j is XCD x's, tile_make_streams)
     const int per_xcd = (num_blocks + 7) >> 3;
-    const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || id >= num_blocks) return;
+    const int id = work ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int)blockIdx.x;
+    if ((work && (int)(blockIdx.x >> 3) >= per_xcd) || id >= num_blocks) return;
     const int t = threadIdx.x;
     // work (optional): the row blocks' passes dealt out to SEVERAL workgroups each -- {block, first pass, end pass,
     // slab}: a block of a few very long rows has far more passes than one workgroup should walk; every workgroup
     // then leaves its accumulators in its own slab and tile_slab_finish adds a row's slabs in order
-    int b = id, p0, p1;
+    // Without work: a STREAM -- block_pass[id] .. block_pass[id + 1] are the passes (in pass_desc, stream order) of all
+    // the blocks this workgroup walks, one after the other without letting the loads run dry in between; a block's last
+    // pass carries kTilePassLast, behind it the accumulators go to y (rows from sblock_rows) and start again at 0.
+    int p0, p1, bi = 0, nrows = 0;
     T *out = nullptr;
     if (work) {
         const int4 w = work[id];
-        b = w.x;
         p0 = w.y;
         p1 = w.z;
         out = slab + (size_t)w.w * rows_per_block;
+        nrows = block_row[w.x + 1] - block_row[w.x];  // <= rows_per_block
     } else {
-        p0 = block_pass[b];
-        p1 = block_pass[b + 1];
+        p0 = block_pass[id];
+        p1 = block_pass[id + 1];
+        bi = stream_block[id];
     }
-    const int row0 = block_row[b];
-    const int nrows = block_row[b + 1] - row0;  // <= rows_per_block
+    const int2 *flush_rows = work ? nullptr : sblock_rows;
     for (int i = t; i < rows_per_block; i += kTileBlock) acc[i] = T(0);
     if (p0 < p1) {
         // entries: four rotating register sets (the current pass + kTileAhead = 3 in flight), x slices: two
@@ -375,7 +409,8 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
         const int pl = p1 - 1;
 #define SPMV_TILE_PASS(cur, fill, wcur, D, DW, DE, P)                                                             \
     tile_pass<T, NT, CH, TRIPS, PACK>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), D, DW, DE, (P) <= pl, \
-                                      stage_ok, probe, acc, xs, wave_r, wave_h, tcol, tkey, tval, x)
+                                      stage_ok, probe, bi, flush_rows, rows_per_block, y, acc, xs, wave_r, wave_h, tcol, tkey,   \
+                                      tval, x)
         SPMV_TILE_ENTRY_REGS(e2);
         SPMV_TILE_ENTRY_REGS(e3);
         // descriptors of passes p .. p + 3 (clamped to the block's last pass), replaced one per pass
@@ -438,11 +473,9 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
         }
 #undef SPMV_TILE_PASS
     }
-    __syncthreads();
-    if (out) {
+    if (out) {  // (a stream has written its rows block by block)
+        __syncthreads();
         for (int i = t; i < nrows; i += kTileBlock) out[i] = acc[i];
-    } else {
-        for (int i = t; i < nrows; i += kTileBlock) y[row0 + i] = acc[i];
     }
 }
 

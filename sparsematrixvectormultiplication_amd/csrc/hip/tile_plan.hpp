@@ -48,6 +48,13 @@ struct TilePlan {
     std::vector<unsigned short> tkey;  // (a packed plan: padding only)
     std::vector<T> tval;
     std::vector<unsigned char> split;  // [M] 1: row is not in the tiles (longer than lmax)
+    // streams (tile_make_streams): what ONE workgroup walks -- the passes of its blocks back to back, so that the
+    // loads of a block's first passes go out while the block before it is still being summed
+    int num_streams = 0;
+    std::vector<int4> spass;           // pass descriptors in stream order, kTilePassLast on a block's last pass
+    std::vector<int> stream_pass;      // [num_streams + 1] first pass (in spass) of every stream
+    std::vector<int> stream_block;     // [num_streams + 1] first block (in sblock_rows) of every stream
+    std::vector<int2> sblock_rows;     // {first row, rows} of the blocks in stream order
 };
 
 namespace tile_detail {
@@ -193,6 +200,10 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
             ++passes;
             i = j;
         }
+        if (passes == 0) {  // a block without entries (empty rows, or only rows beyond the limit): one pass of none, so
+            out.pass_desc.push_back(int4{(int)out.tcol.size(), 0, 0, pack ? ((16 / (int)sizeof(T)) | kTilePassPacked) : 0});  // that whoever
+            passes = 1;                                                                           // walks it writes its zeros
+        }
         out.passes_per_block.push_back(passes);
     }
 }
@@ -300,6 +311,49 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
     plan.tkey.insert(plan.tkey.end(), (size_t)kTileChunkMax, 0);
     plan.tval.insert(plan.tval.end(), (size_t)kTileChunkMax, T(0));
     return true;
+}
+
+// Streams over a built plan: the chip holds `places` workgroups at once; with more blocks than that, workgroup s of XCD x
+// (blockIdx = x + 8 s) walks blocks s, s + W, s + 2 W, ... of that XCD's contiguous eighth of the blocks (W = places / 8
+// workgroups per XCD), i.e. in every 'round' the workgroups of an XCD still sit on neighbouring blocks, which keeps the
+// band of x they gather from together inside that XCD's L2 (tile_kernels.hpp).  Only the descriptors are re-ordered; the
+// entries stay where they are.
+template <typename T>
+void tile_make_streams(TilePlan<T> &plan, int places) {
+    const int B = plan.num_blocks;
+    places = std::max(8, places / 8 * 8);
+    std::vector<std::vector<int>> streams;
+    if (B <= places) {
+        // (workgroup ids go round-robin over the XCDs: stream x + 8 j = block j of XCD x's eighth; with a block count
+        // that is no multiple of 8 a few streams stay empty)
+        const int per_xcd = (B + 7) / 8;
+        streams.assign((size_t)(per_xcd * 8), {});
+        for (int b = 0; b < B; ++b) streams[(size_t)((b / per_xcd) + 8 * (b % per_xcd))].push_back(b);
+    } else {
+        const int per_xcd = (B + 7) / 8, W = places / 8;
+        streams.assign((size_t)places, {});
+        for (int b = 0; b < B; ++b) {
+            const int x = b / per_xcd, local = b % per_xcd;
+            streams[(size_t)(x + 8 * (local % W))].push_back(b);
+        }
+    }
+    plan.num_streams = (int)streams.size();
+    plan.spass.clear();
+    plan.sblock_rows.clear();
+    plan.stream_pass.assign(1, 0);
+    plan.stream_block.assign(1, 0);
+    for (const auto &st : streams) {
+        for (int b : st) {
+            for (int p = plan.block_pass[(size_t)b]; p < plan.block_pass[(size_t)b + 1]; ++p) {
+                int4 d = plan.pass_desc[(size_t)p];
+                if (p + 1 == plan.block_pass[(size_t)b + 1]) d.w |= kTilePassLast;
+                plan.spass.push_back(d);
+            }
+            plan.sblock_rows.push_back(int2{plan.block_row[(size_t)b], plan.block_row[(size_t)b + 1] - plan.block_row[(size_t)b]});
+        }
+        plan.stream_pass.push_back((int)plan.spass.size());
+        plan.stream_block.push_back((int)plan.sblock_rows.size());
+    }
 }
 
 }  // namespace spmv
