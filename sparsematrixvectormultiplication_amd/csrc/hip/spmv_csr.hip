@@ -214,8 +214,8 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
             if (row_len[r] <= g_tile_lmax) in_tiles += row_len[r];
         const long long full = std::max(1, (Ml + rb - 1) / rb);
         const int b0 = (int)tile_cut_rows(Ml, row_len, g_tile_lmax, rb, std::max<long long>(chunk, (in_tiles + full - 1) / full)).size() - 1;
-        // (a matrix whose blocks do not fill one round keeps them: thinner blocks would each read more of x)
-        const int kmax = b0 > places ? (b0 + places - 1) / places : 0;
+        // (a matrix whose blocks fill less than 90 % of one round keeps them: thinner blocks would each read more of x)
+        const int kmax = b0 * 10LL > places * 9LL ? (b0 + places - 1) / places : 0;
         for (int k = 1; k <= kmax; ++k) {
             const long long want = (long long)k * places * 197 / 200;
             const long long t = std::max<long long>(chunk, (in_tiles + want - 1) / want);
