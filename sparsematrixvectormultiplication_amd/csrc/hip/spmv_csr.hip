@@ -109,9 +109,9 @@ bool build_long_tiles(int M, int N, const int *rp, const int *row_len, const int
             return false;
     }
     for (int r : rows) split[(size_t)r] = 0;
-    // work items: ~4096 of them over all blocks, at least 4 passes each
+    // work items: ~tile_items (1008: two rounds of the 512 places) of them over all blocks, at least 4 passes each
     const long long passes = (long long)plan.pass_desc.size();
-    const int per_item = (int)std::max<long long>(4, (passes + 4095) / 4096);
+    const int per_item = (int)std::max<long long>(4, (passes + g_tile_items - 1) / g_tile_items);
     work.clear();
     item_first.assign(1, 0);
     for (int b = 0; b < plan.num_blocks; ++b) {

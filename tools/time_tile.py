@@ -81,6 +81,7 @@ for name in want:
             set_tuning("tile_long", int(os.environ.get("TILE_LONG", "1")))
             set_tuning("tile_fit", int(os.environ.get("TILE_FIT", "1")))
             set_tuning("tile_streams", int(os.environ.get("TILE_STREAMS", "1")))
+            set_tuning("tile_items", int(os.environ.get("TILE_ITEMS", "1008")))
             set_tuning("tile_pack", dn_pack)
             set_tuning("tile_lmax", int(os.environ.get("TILE_LMAX", "1024")))
             set_tuning("stream_tile", 1)
