@@ -134,7 +134,8 @@ int spmv_hip_flush_cache(size_t bytes);
  *                     "tile_fit" 1 | 0 (with tile_rows 0) the number of row blocks is fitted to whole rounds of the
  *                     workgroups the chip holds at once (512 banded / 256 scattered), blocks up to the tallest the LDS takes;
  *                     "tile_streams" 1 | 0 one csr_tile workgroup per place of the chip walks several row blocks back to
- *                     back (0: one workgroup per block); "tile_items" (1008) work items the long rows' passes are dealt out to;
+ *                     back (0: one workgroup per block); "tile_places" 0 (the chip's: 2 or 1 per CU) | a multiple of 8: how
+ *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
  *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 40 KiB window and
  *                     staged, keys in the column words, kernel instantiation without gather code) unless its passes
  *                     would average fewer than 256 entries; 0: always the plan with gather passes

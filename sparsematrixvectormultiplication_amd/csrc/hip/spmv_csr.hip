@@ -207,7 +207,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     // at in_tiles / (98.5 % of k rounds' places) entries, come out as at most k rounds' worth.
     long long target = 0;
     if (!g_tile_rows && g_tile_balance && g_tile_fit) {
-        const int places = (tb.scattered ? 1 : 2) * g_num_cus;
+        const int places = g_tile_places ? g_tile_places : (tb.scattered ? 1 : 2) * g_num_cus;
         const int rows_max = tb.scattered ? scattered_rows_max : banded_rows_max;
         long long in_tiles = 0;
         for (int r = 0; r < Ml; ++r)
@@ -243,7 +243,8 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     if (tb.have_tiles && g_stream_tile < 0 && !g_tile_long && tb.tiles.entries * 2 < nz) tb.have_tiles = false;
     if (!tb.have_tiles) return;
     // one workgroup per place of the chip walks several blocks back to back (tile_streams 0: one workgroup per block)
-    tile_make_streams(tb.tiles, g_tile_streams ? (tb.scattered ? 1 : 2) * g_num_cus : 0x3fffffff);
+    // (tile_places: tests walk long streams on small matrices)
+    tile_make_streams(tb.tiles, !g_tile_streams ? 0x3fffffff : g_tile_places ? g_tile_places : (tb.scattered ? 1 : 2) * g_num_cus);
     // The rows beyond the tile limit, compacted: their own row blocks (<= 2048 of them each), same passes -- so many
     // entries per column range that every pass is staged: the long rows' x lookups happen in LDS at the HBM streaming
     // rate instead of going through the gather path -- and a block's passes dealt out to many workgroups.

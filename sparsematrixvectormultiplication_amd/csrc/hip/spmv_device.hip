@@ -48,6 +48,7 @@ int g_tile_probe = 0;
 int g_skew_rows = 1;
 int g_tile_fit = 1;
 int g_tile_streams = 1;
+int g_tile_places = 0;
 int g_tile_items = 1008;  // two rounds of the 512 places: 1.222 ms on the power-law matrix against 1.248 with 4096, 1.231 with 504
 int g_tile_pack = 1;
 int g_tile_long = 1;
@@ -184,6 +185,9 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_tile_long = value;
     } else if (!strcmp(key, "tile_balance")) {
         g_tile_balance = value != 0;
+    } else if (!strcmp(key, "tile_places")) {
+        if (value < 0 || (value & 7) || value > 4096) return fail("set_tuning: tile_places must be 0 (the chip's) or a multiple of 8 up to 4096");
+        g_tile_places = value;
     } else if (!strcmp(key, "tile_items")) {
         if (value < 8 || value > 65536) return fail("set_tuning: tile_items must be 8..65536");
         g_tile_items = value;

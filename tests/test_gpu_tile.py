@@ -37,7 +37,8 @@ class tuned:
 
     def __exit__(self, *exc):
         defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 16, "stream_kind": -1,
-                    "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1}
+                    "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1, "tile_places": 0,
+                    "tile_streams": 1, "tile_fit": 1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 
@@ -300,7 +301,7 @@ def test_tile_kernel_random_shapes(gpu, oracle):
     poisoned first and the launch repeated (bit-reproducible)."""
     rng = np.random.default_rng(20260)
     packed_seen = plain_seen = 0
-    for case in range(48):
+    for case in range(64):
         dtype = np.float64 if case % 3 else np.float32
         M = int(rng.integers(1, 30_000))
         N = int(rng.integers(1, 200_000)) if case % 4 else M
@@ -319,8 +320,13 @@ def test_tile_kernel_random_shapes(gpu, oracle):
         x = rng.uniform(-1, 1, N).astype(dtype)
         y_ref = reference(oracle, rp, col, val, x, dtype)
         rows_per_block = int(rng.choice([256, 512, 2048, 4096]))
+        # (tile_places: streams of many blocks on these small matrices -- the chip's own 512 / 256 places would give
+        # every block its own workgroup; tile_rows 0 with few places exercises the fitted block count as well)
+        places = int(rng.choice([0, 8, 16, 64]))
+        if case % 8 == 7:
+            rows_per_block = 0
         with tuned(stream_tile=1, stream_local=0, tile_rows=rows_per_block, tile_pack=int(case % 6 != 5),
-                   tile_lmax=int(rng.choice([64, 1024]))):
+                   tile_lmax=int(rng.choice([64, 1024])), tile_places=places, tile_streams=int(case % 11 != 10)):
             with sp.CsrDevice(M, N, rp, col, val) as dev:
                 info = dev.info()
                 if info["stream_kernel"] != 3:
@@ -330,5 +336,6 @@ def test_tile_kernel_random_shapes(gpu, oracle):
                 else:
                     plain_seen += 1
                 check(dev, x, y_ref, rp, col, val, dtype,
-                      f"case {case}: M={M} N={N} mean={mean} sigma={sigma} rows={rows_per_block} {np.dtype(dtype).name}")
+                      f"case {case}: M={M} N={N} mean={mean} sigma={sigma} rows={rows_per_block} places={places} "
+                      f"{np.dtype(dtype).name}")
     assert packed_seen >= 8 and plain_seen >= 8, (packed_seen, plain_seen)
