@@ -309,8 +309,10 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
             wave_h[u * kTileWaves + wave] = h;
         }
         // what lane s's tail run collects: the chain starting at lane s + 1
-        chain[u] = lane_down(r, 1);
-        closed[u] = lane_down(h, 1) != 0;
+        // (wave_shl:1 -- a DPP move across the whole wavefront, gfx9 only -- where __shfl_down would take three trips
+        // through the LDS crossbar; lane 63 is overwritten below)
+        chain[u] = row_down<0x130>(r);
+        closed[u] = dpp_i32<0x130>(h) != 0;
         if (lane == 63) {
             chain[u] = T(0);
             closed[u] = false;
