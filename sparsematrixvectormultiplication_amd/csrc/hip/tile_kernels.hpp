@@ -130,11 +130,6 @@ __device__ __forceinline__ void tile_issue_window(v4u (&rw)[TRIPS], const int4 d
     }
 }
 
-template <typename T>
-__device__ __forceinline__ T lane_down(T v, int delta) {  // value of lane + delta (own value past lane 63)
-    return __shfl_down(v, delta, 64);
-}
-
 // value of lane + N inside the lane's row of 16 (DPP row_shl: a VALU move, no LDS crossbar); 0 past the row's end
 template <int CTRL>
 __device__ __forceinline__ double row_down(double v) {
