@@ -369,11 +369,13 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
                          "kernel": ("csr_stream", "csr_stream_local", "csr_stream_short")[info["stream_kernel"]],
                          "format_bytes": info["stream_bytes"] or info["algo_bytes"],
                          "us": round(float(ms.mean()) * 1e3, 2)}}
-    if which in ("road_like", "wide_band"):
+    if which in ("road_like", "wide_band", "dense_band"):
         # two of tools/matrix_zoo.py's classes without an x-window plan (the reference's own list is full of such
         # graph / circuit matrices, result/result_cuda.csv:2-31): what the 2-D tile kernel makes of them
         import scipy.sparse as sps
-        n, per_row, sigma = (12_000_000, 3, 2000.0) if which == "road_like" else (2_000_000, 30, 20000.0)
+        # (dense_band: rows and entries per row of the reference's largest matrix, Cube_Coup_dt0, result_cuda.csv:3)
+        n, per_row, sigma = {"road_like": (12_000_000, 3, 2000.0), "wide_band": (2_000_000, 30, 20000.0),
+                             "dense_band": (2_164_760, 59, 2500.0)}[which]
         rng = np.random.default_rng(2026)
         r = np.repeat(np.arange(n, dtype=np.int64), per_row)
         c = np.clip(r + np.rint(rng.normal(0, sigma, len(r))).astype(np.int64), 0, n - 1)
@@ -761,7 +763,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_also and args.workload == "nlpkkt":
         dev.close()
         result["also"] = []
-        for which in ("cant_csr", "cant_hll", "fem_large_csr", "powerlaw_f32", "road_like", "wide_band"):
+        for which in ("cant_csr", "cant_hll", "fem_large_csr", "powerlaw_f32", "road_like", "wide_band", "dense_band"):
             try:  # side numbers must never lose the headline line, nor each other
                 result["also"].append(side_measurement(sp, synth, which, K, W,
                                                        cpu_sweep=which == "cant_hll" and not (args.no_cpu_baseline or args.no_cpu_sweep)))
