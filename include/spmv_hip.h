@@ -182,6 +182,11 @@ int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx
  * kernels, widest staged window (columns). */
 int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
                                  int rows_per_block, int lmax, int density, int chunk, int balance, long long *stats);
+/* What upload WOULD decide for a CSR structure under the current tunings (host only, values taken as 1): stats[10] =
+ * a tile plan is built (0: the gather kernels keep the matrix), packed plan, scattered geometry (one workgroup per
+ * CU), rows per block the kernel is launched for, row blocks, streams (workgroups), passes, rows of the tallest
+ * block, work items of the long rows' plan, entries in the ordinary tiles. */
+int spmv_hip_csr_tile_auto_plan(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, long long *stats);
 /* COO triplets (0-based, any order) -> a CSR handle, built ON THE DEVICE (upload of the
  * triplets, one stable radix sort by (row, column), row pointers and the x-window plan by kernels).  Same
  * matrix as convert_in_csr + spmv_hip_csr_upload_matrix; entries that repeat one (row, column) keep file

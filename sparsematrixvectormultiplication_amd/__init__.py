@@ -11,7 +11,7 @@ from .host import (HACK_SIZE, ITERATION_SKIP, CsrHost, HllHost, PreMatrix,  # no
                    calculate_flops, compute_difference_metrics, compute_difference_metrics_gpu,
                    convert_in_csr, convert_to_hll, init_vector_at_one, partition_rows,
                    prepare_thread_distribution, prepare_thread_distribution_hll,
-                   read_matrix_market, csr_plan_check, csr_tile_plan_check, hll_plan_check, partition_hacks, hack_bounds_to_rows, save_csr_binary, load_csr_binary, load_csr_cached)
+                   read_matrix_market, csr_plan_check, csr_tile_plan_check, csr_tile_auto_plan, hll_plan_check, partition_hacks, hack_bounds_to_rows, save_csr_binary, load_csr_binary, load_csr_cached)
 from .device import (CSR_AUTO, CSR_STREAM, CSR_SUBWAVE, CSR_THREAD_ROW, CSR_VARIANTS,  # noqa: F401
                      CSR_WAVE_ROW, HLL_AUTO, HLL_LDS, HLL_SUBWAVE, HLL_THREAD_ROW, HLL_VARIANTS,
                      CsrDevice, HllDevice, SpmvHipError, device_count, device_name, flush_cache,

@@ -193,6 +193,7 @@ _PROTOTYPES = {
     "spmv_hip_csr_plan_check": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p]),
     "spmv_hip_csr_tile_plan_check": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
+    "spmv_hip_csr_tile_auto_plan": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, C.POINTER(C.c_longlong)]),
     "spmv_hip_csr_power_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, c_double_p,
                                              c_float_p]),
     "spmv_hip_csr_needed_ranges": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),

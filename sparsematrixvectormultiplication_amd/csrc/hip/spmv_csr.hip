@@ -998,6 +998,47 @@ extern "C" int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, co
     });
 }
 
+// What upload would decide for this structure (host only, current tunings): tile_plan_all's choices.
+template <typename T>
+static int tile_auto_plan(int M, int N, const int *rp, const int *col, long long *stats) {
+    const long long nz = rp[M];
+    std::vector<T> val((size_t)nz, T(1));
+    std::vector<int> row_len((size_t)M);
+    for (int r = 0; r < M; ++r) row_len[(size_t)r] = rp[r + 1] - rp[r];
+    TileBuild<T> tb;
+    tile_plan_all<T>(M, N, rp, row_len.data(), rp, nz, col, val.data(), tb);
+    for (int k = 0; k < 10; ++k) stats[k] = 0;
+    stats[0] = tb.have_tiles;
+    if (!tb.have_tiles) return 0;
+    int tallest = 0;
+    for (int b = 0; b < tb.tiles.num_blocks; ++b)
+        tallest = std::max(tallest, tb.tiles.block_row[(size_t)b + 1] - tb.tiles.block_row[(size_t)b]);
+    stats[1] = tb.packed;
+    stats[2] = tb.scattered;
+    stats[3] = tb.tiles.rows_per_block;
+    stats[4] = tb.tiles.num_blocks;
+    stats[5] = tb.tiles.num_streams;
+    stats[6] = (long long)tb.tiles.pass_desc.size();
+    stats[7] = tallest;
+    stats[8] = tb.have_long_tiles ? (long long)tb.lt_work.size() : 0;
+    stats[9] = tb.tiles.entries;
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_tile_auto_plan(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes,
+                                           long long *stats) {
+    if (M < 0 || N < 0 || !row_ptr || !stats || (value_bytes != 4 && value_bytes != 8)) return fail("tile_auto_plan: bad arguments");
+    const long long nz = row_ptr[M];
+    if (nz > 0 && !col_idx) return fail("tile_auto_plan: col_idx is NULL");
+    for (int r = 0; r < M; ++r)
+        if (row_ptr[r + 1] < row_ptr[r]) return fail("tile_auto_plan: row_ptr decreases at row %d", r);
+    for (long long e = 0; e < nz; ++e)
+        if ((unsigned)col_idx[e] >= (unsigned)N) return fail("tile_auto_plan: column %d outside [0, %d)", col_idx[e], N);
+    return guarded("tile_auto_plan", [&] {
+        return value_bytes == 8 ? tile_auto_plan<double>(M, N, row_ptr, col_idx, stats) : tile_auto_plan<float>(M, N, row_ptr, col_idx, stats);
+    });
+}
+
 // a whole fp64 matrix whose col / val already sit on the device (spmv_coo.hip)
 int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_val, spmv_csr_dev **out) {
     return guarded("csr_adopt", [&] { return csr_upload_impl<double>(M, N, row_ptr_host, nullptr, nullptr, 0, M, out, d_col, d_val); });

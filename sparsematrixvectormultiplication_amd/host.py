@@ -272,6 +272,19 @@ def csr_tile_plan_check(M, N, row_ptr, col_idx, value_bytes=8, rows_per_block=20
     return dict(zip(names + tuple("packed_" + n for n in names), (int(v) for v in stats)))
 
 
+def csr_tile_auto_plan(M, N, row_ptr, col_idx, value_bytes=8):
+    """What upload would decide about the csr_tile plan of this structure under the current tunings (host only)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    stats = np.zeros(10, dtype=np.int64)
+    if nat.lib().spmv_hip_csr_tile_auto_plan(int(M), int(N), _ip(row_ptr), _ip(col_idx), int(value_bytes),
+                                             stats.ctypes.data_as(C.POINTER(C.c_longlong))) != 0:
+        raise ValueError(nat.lib().spmv_hip_last_error().decode())
+    names = ("tiles", "packed", "scattered", "rows_per_block", "blocks", "streams", "passes", "tallest_block",
+             "long_items", "entries")
+    return dict(zip(names, (int(v) for v in stats)))
+
+
 def hll_plan_check(hll: "HllHost"):
     """Host-only self-check of the HLL upload-time plan (spmv_hip_hll_plan_check); returns its stats."""
     stats = np.zeros(4, dtype=np.int32)

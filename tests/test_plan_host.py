@@ -178,3 +178,50 @@ def test_tile_plan_on_golden_matrices(name):
     csr = sp.convert_in_csr(sp.read_matrix_market(golden_path(name)))
     st = sp.csr_tile_plan_check(csr.M, csr.N, csr.row_ptr, csr.col_idx, 8, 256, lmax=64)
     assert st["entries"] + 0 <= csr.nz
+
+
+def test_tile_auto_plan_decisions():
+    """What upload decides about the csr_tile plan (spmv_hip_csr_tile_auto_plan, host only): a band gets the packed
+    plan, uniformly scattered columns the plan with gather passes and tall blocks -- but only from 1.5 M columns on --
+    and the number of row blocks is fitted to whole rounds of the workgroup places (here 16 places, so that a small
+    matrix shows it): at most k x places blocks with the last round at least 90 % full, every block within the
+    tallest the LDS takes, every block in exactly one stream."""
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    rng = np.random.default_rng(5)
+    try:
+        set_tuning("tile_places", 16)
+        # a band, forced (the auto rule wants 2^20 rows)
+        set_tuning("stream_tile", 1)
+        M = N = 300_000
+        rp, col = _scattered(rng, M, N, 5, sigma=900)
+        st = sp.csr_tile_auto_plan(M, N, rp, col, 8)
+        assert st["tiles"] and st["packed"] and not st["scattered"] and st["entries"] == rp[-1]
+        assert st["tallest_block"] <= st["rows_per_block"] == 4864 and st["streams"] == 16
+        rounds = -(-st["blocks"] // 16)
+        assert st["blocks"] <= rounds * 16 and st["blocks"] >= 0.9 * rounds * 16, st
+        st32 = sp.csr_tile_auto_plan(M, N, rp, col, 4)
+        assert st32["packed"] and st32["rows_per_block"] == 9984
+        # the same without the fitting: blocks of 4096 fp64 rows
+        set_tuning("tile_fit", 0)
+        plain = sp.csr_tile_auto_plan(M, N, rp, col, 8)
+        assert plain["rows_per_block"] == 4096 and plain["blocks"] >= M // 4096
+        set_tuning("tile_fit", 1)
+        # one workgroup per block
+        set_tuning("tile_streams", 0)
+        assert sp.csr_tile_auto_plan(M, N, rp, col, 8)["streams"] >= st["blocks"]
+        set_tuning("tile_streams", 1)
+        # scattered columns: gather passes, one workgroup per CU geometry, blocks as tall as the LDS takes
+        M, N = 200_000, 2_000_000
+        rp, col = _scattered(rng, M, N, 6)
+        sc = sp.csr_tile_auto_plan(M, N, rp, col, 8)
+        assert sc["tiles"] and not sc["packed"] and sc["scattered"] and sc["tallest_block"] <= sc["rows_per_block"] <= 15104
+        rounds = -(-sc["blocks"] // 16)
+        assert sc["blocks"] <= rounds * 16
+        # auto: scattered columns get tiles only from 1.5 M columns on, whatever the rows
+        set_tuning("stream_tile", -1)
+        assert sp.csr_tile_auto_plan(M, N, rp, col, 8)["tiles"] == 1
+        rp2, col2 = _scattered(rng, M, 1_000_000, 6)
+        assert sp.csr_tile_auto_plan(M, 1_000_000, rp2, col2, 8)["tiles"] == 0
+    finally:
+        for k, v in (("tile_places", 0), ("stream_tile", -1), ("tile_fit", 1), ("tile_streams", 1)):
+            set_tuning(k, v)
