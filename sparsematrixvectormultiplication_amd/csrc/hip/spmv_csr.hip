@@ -146,7 +146,7 @@ struct TileBuild {
 //    too many of them are on the way at once: the tallest blocks (up to 16384 rows) that still leave ~2 per CU, ONE
 //    workgroup per CU.  Power-law matrix (fp32, 2^24 rows): 2.90 ms at 8192 rows, 1.97 ms at 16384 with one
 //    workgroup per CU, 2.39 ms with two.
-constexpr int kTileGatherMinCols = 1536 * 1024;  // (auto) columns from which a tile plan with gather passes is built
+constexpr int kTileGatherMinCols = 800000;  // (auto) columns from which a tile plan with gather passes is built
 
 template <typename T>
 void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, const int *rp, long long nz, const int *hcol,
@@ -194,11 +194,10 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.packed = want_pack && !tb.scattered;
-    // (auto) plans with gather passes pay once x has outgrown the L2s -- from 1.5 M columns on: with 8.7 MB of x (1.09 M fp64 columns; the
-    // reference's roadNet-PA / webbase-1M sizes) the gather kernels are 10-25 % faster (44 vs 55 us at 3 uniformly random
-    // columns per row, 123 vs 136 at 10, 95 vs 102 us power-law fp32), with 16 MB the tiles are (70 vs 94, 168 vs 292 us);
-    // a packed plan wins at that size as well (road-like 1.09 M rows: 24 vs 29 us)
-    // (in columns rather than bytes: fp32 power-law with 2^21 columns = 8.4 MB of x is 23 % faster in tiles)
+    // (auto) tile plans pay from about 800 000 rows / columns on (kTileMinRows, kTileGatherMinCols): 5 uniformly random
+    // columns per row tie with the gather kernel at 750 000 rows (37.4 vs 37.9 us) and lose at 500 000 (28 vs 23 us); at
+    // 1.09 M rows 3 per row win 37 vs 44 us, power-law fp32 74 vs 107 us, a road-like band 24 vs 29 us.  (Before the block
+    // count was fitted to rounds the break-even was 1.5 M columns: 2 x 256 short blocks on 256 places.)
     if (g_stream_tile < 0 && !tb.packed && N < kTileGatherMinCols) return;
     // How many blocks: equal-work blocks finish together, so the kernel runs in ROUNDS of as many blocks as the chip
     // holds at once (2 per CU banded, 1 scattered) and a last round of a few blocks costs a whole one -- 530 blocks on
@@ -610,7 +609,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     // pieces cut at column stripes.
     TileBuild<T> tb;
     if (!have_local && nz > 0 && g_stream_tile != 0 && g_stream_cap == 0 &&
-        (g_stream_tile == 1 || (long long)Ml >= 512LL * 2048)) {
+        (g_stream_tile == 1 || (long long)Ml >= kTileMinRows)) {
         std::vector<int> col_copy;
         std::vector<T> val_copy;
         const int *hcol = col_idx ? col_idx + e0 : nullptr;
@@ -1052,7 +1051,7 @@ int csr_tiles_from_rows_f64(int M_local, int M_total, int row0, int N, const int
                             long long entries, const int *col, const double *val, spmv_csr_dev **out) {
     *out = nullptr;
     if (M_local <= 0 || entries <= 0 || g_stream_tile == 0) return 0;
-    if (g_stream_tile < 0 && (long long)M_local < 512LL * 2048) return 0;
+    if (g_stream_tile < 0 && (long long)M_local < kTileMinRows) return 0;
     return guarded("hll tile plan", [&] {
         TileBuild<double> tb;
         tile_plan_all<double>(M_local, N, row_begin, row_len, nullptr, entries, col, val, tb);

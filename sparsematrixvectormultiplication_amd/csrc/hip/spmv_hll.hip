@@ -212,7 +212,14 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
     if (!rc && m->local_blocks > 0) rc = hll_fill_row_segments(m);
     // no x-window plan (columns too scattered): the 2-D tiles over the slab's rows, padding slots included -- the
     // rows of hack h are maxnz[h] slots each, starting at hack_off[h] + i * maxnz[h] (needs the slab on the host)
-    if (!rc && m->local_blocks == 0 && ja_host && as_host && true_slots > 0 && off[H] < 0x7fffffffLL) {
+    // (auto: not for a skewed slab -- a hack whose rows are 16 times the mean is 32 rows of mostly padding, and tiles
+    // over such rows lose to hll_lds: webbase-like stand-in, 1 M rows, 455 vs 159 us)
+    bool skewed = false;
+    if (g_stream_tile < 0 && total_rows > 0) {
+        const long long mean = std::max<long long>(1, off[H] / total_rows);
+        for (int h = 0; h < H && !skewed; ++h) skewed = mz[(size_t)h] > 16 * mean;
+    }
+    if (!rc && !skewed && m->local_blocks == 0 && ja_host && as_host && true_slots > 0 && off[H] < 0x7fffffffLL) {
         std::vector<int> row_begin((size_t)total_rows), row_len((size_t)total_rows);
         for (int r = 0; r < total_rows; ++r) {
             const int h = r / kHack;
@@ -529,7 +536,7 @@ static int spmv_hip_hll_from_csr_body(const spmv_csr_dev *csr, spmv_hll_dev **ou
             e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
             // (the values too: a slab without an x-window plan may get the tile plan, built on the host)
-            if (g_stream_tile != 0 && (g_stream_tile == 1 || (long long)M >= 512LL * 2048)) {
+            if (g_stream_tile != 0 && (g_stream_tile == 1 || (long long)M >= kTileMinRows)) {
                 as_host.resize((size_t)S);
                 e = hipMemcpy(as_host.data(), m->AS, (size_t)S * sizeof(double), hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { rc = fail("hll_from_csr: AS download failed: %s", hipGetErrorString(e)); break; }

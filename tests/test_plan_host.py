@@ -182,7 +182,7 @@ def test_tile_plan_on_golden_matrices(name):
 
 def test_tile_auto_plan_decisions():
     """What upload decides about the csr_tile plan (spmv_hip_csr_tile_auto_plan, host only): a band gets the packed
-    plan, uniformly scattered columns the plan with gather passes and tall blocks -- but only from 1.5 M columns on --
+    plan, uniformly scattered columns the plan with gather passes and tall blocks -- but only from 800 000 columns on --
     and the number of row blocks is fitted to whole rounds of the workgroup places (here 16 places, so that a small
     matrix shows it): at most k x places blocks with the last round at least 90 % full, every block within the
     tallest the LDS takes, every block in exactly one stream."""
@@ -217,11 +217,11 @@ def test_tile_auto_plan_decisions():
         assert sc["tiles"] and not sc["packed"] and sc["scattered"] and sc["tallest_block"] <= sc["rows_per_block"] <= 15104
         rounds = -(-sc["blocks"] // 16)
         assert sc["blocks"] <= rounds * 16
-        # auto: scattered columns get tiles only from 1.5 M columns on, whatever the rows
+        # auto: scattered columns get tiles only from 800 000 columns on, whatever the rows
         set_tuning("stream_tile", -1)
         assert sp.csr_tile_auto_plan(M, N, rp, col, 8)["tiles"] == 1
-        rp2, col2 = _scattered(rng, M, 1_000_000, 6)
-        assert sp.csr_tile_auto_plan(M, 1_000_000, rp2, col2, 8)["tiles"] == 0
+        rp2, col2 = _scattered(rng, M, 600_000, 6)
+        assert sp.csr_tile_auto_plan(M, 600_000, rp2, col2, 8)["tiles"] == 0
     finally:
         for k, v in (("tile_places", 0), ("stream_tile", -1), ("tile_fit", 1), ("tile_streams", 1)):
             set_tuning(k, v)
