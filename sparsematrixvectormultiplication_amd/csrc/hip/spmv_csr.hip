@@ -718,6 +718,12 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     int lanes = pow2_floor(std::max(2, (int)(mean / 2.0 + 0.5)));
     m->lanes_per_row = std::min(32, std::max(2, lanes));
     m->auto_variant = SPMV_CSR_STREAM;
+    // Mid-size matrices that get neither plan (scattered columns, below the tile plans' size): the lane-group kernel
+    // beats the gather stream kernels by 3-10 % on every such stand-in of the reference's list (cop20k_A-size 19.2 vs
+    // 21.2 us, PR02R-size 37 vs 41, amazon0302-size 12.1 vs 13.5; profiles/r2_reference_list_stand_ins.md) -- unless rows
+    // are skewed (its lanes per row are fixed), and not on large ones (road-like 12 M rows: 282 vs 255 us).
+    if (!have_local && !tb.have_tiles && nz < (20LL << 20) && max_row <= std::max(64.0, 8.0 * mean))
+        m->auto_variant = SPMV_CSR_SUBWAVE;
     *out = m;
     return 0;
 }
