@@ -128,7 +128,7 @@ int spmv_hip_flush_cache(size_t bytes);
  *     "stream_tile"   -1 (auto) | 0 | 1   build the 2-D tile plan (csr_tile) when the matrix gets no x-window plan;
  *                     "tile_rows" 0 (auto: 32 KiB of accumulators for banded matrices, up to 16384 rows for scattered
  *                     ones) | a multiple of 256 in 256..16384 rows per block; "tile_lmax" (1024) longest row kept in
- *                     the ordinary tiles; "tile_density" (16) columns per entry up to which a pass is staged in LDS;
+ *                     the ordinary tiles; "tile_density" (4) columns per entry up to which a pass is staged in LDS;
  *                     "tile_balance" 1 | 0 row blocks of equal entry / row counts; "tile_long" 1 | 0 | 2 a tile plan of
  *                     their own for the rows beyond tile_lmax (0: split-row kernels, 2: however few they are);
  *                     "tile_fit" 1 | 0 (with tile_rows 0) the number of row blocks is fitted to whole rounds of the
@@ -136,7 +136,7 @@ int spmv_hip_flush_cache(size_t bytes);
  *                     "tile_streams" 1 | 0 one csr_tile workgroup per place of the chip walks several row blocks back to
  *                     back (0: one workgroup per block); "tile_places" 0 (the chip's: 2 or 1 per CU) | a multiple of 8: how
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
- *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 40 KiB window and
+ *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 32 KiB window and
  *                     staged, keys in the column words, kernel instantiation without gather code) unless its passes
  *                     would average fewer than 256 entries; 0: always the plan with gather passes
  *   read at launch

@@ -139,7 +139,7 @@ struct TileBuild {
 //
 // Rows per block (auto): two regimes, told apart on a sample of the rows.
 //  * banded (most entries in passes that can be staged): 32 KiB of accumulators (4096 fp64 / 8192 fp32 rows), so
-//    that two workgroups with their 40 KiB x slices share a CU (road-like, wide band: measured best of 2048 / 4096 /
+//    that two workgroups with their 32 KiB x slices share a CU (road-like, wide band: measured best of 2048 / 4096 /
 //    8192);
 //  * scattered (gather passes): what matters is that a pass spans little of x (the band all blocks gather from
 //    together must fit L2), that the blocks run in few rounds (a new round starts again at column 0) and that not
@@ -162,7 +162,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     constexpr int banded_rows_max = tile_banded_rows_max<T>();
     constexpr int scattered_rows_max = tile_scattered_rows_max<T>();
     bool want_pack = g_tile_pack != 0;
-    // (... or slices several times the size of the entries they serve: 40 KiB of x out of L2 for a few hundred entries
+    // (... or slices several times the size of the entries they serve: 32 KiB of x out of L2 for a few hundred entries
     // costs as much as gathering them, measured on 30 uniformly random columns per row of a 1 M-column matrix)
     auto pack_pays = [&](const TilePlan<T> &p) {
         return p.entries >= (long long)p.pass_desc.size() * (chunk / 8) &&

@@ -43,7 +43,7 @@ int g_stream_kind = -1;
 int g_stream_tile = -1;
 int g_tile_rows = 0;
 int g_tile_lmax = 1024;
-int g_tile_density = 16;
+int g_tile_density = 4;
 int g_tile_probe = 0;
 int g_skew_rows = 1;
 int g_tile_fit = 1;

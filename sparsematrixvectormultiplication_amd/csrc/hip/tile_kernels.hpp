@@ -60,14 +60,14 @@ constexpr int kTileWlenMask = (1 << 20) - 1;  // pass_desc.w: the staged columns
 constexpr int kTilePackShift = 14;
 constexpr unsigned kTilePackColMask = (1u << kTilePackShift) - 1;
 constexpr int kTileTripBytes = kTileBlock * 16;  // x bytes one staging trip of the workgroup copies
-constexpr int kTileTrips = 5;        // trips per pass: windows of up to 40 KiB
+constexpr int kTileTrips = 4;        // trips per pass: windows of up to 32 KiB
 constexpr int kTileAhead = 3;        // passes whose entries are in flight beyond the one being worked on
 // (a compact variant -- 24 KiB windows, 1 pass ahead, 79 VGPRs, three workgroups per CU -- was measured and is no
 // faster: road-like 191 us at 3072 rows against 173 us for this one at 4096, profiles/r2_ab_csr_tile.txt)
 constexpr int kTileSlotBytes = 256;  // LDS in front of the accumulators: one (sum, closed) slot per wavefront and quad
 constexpr int kTileLdsBytes = 160 * 1024;  // a CU's LDS
 // the tallest row blocks: two workgroups per CU (banded plans) / one (scattered), each with its wave slots, its
-// accumulators and a full 40 KiB x slice
+// accumulators and a full 32 KiB x slice
 template <typename T>
 constexpr int tile_banded_rows_max() {
     return (kTileLdsBytes / 2 - kTileSlotBytes - kTileTrips * kTileTripBytes) / (int)sizeof(T) / 256 * 256;

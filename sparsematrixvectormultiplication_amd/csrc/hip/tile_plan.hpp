@@ -233,7 +233,7 @@ template <typename T>
 bool tile_build(int M, int N, const int *row_begin, const int *row_len, const int *col, const T *val, int rows_per_block,
                 int lmax, int density, int chunk, bool balance, int pos_bits, TilePlan<T> &plan, bool pack = true,
                 long long target_entries = 0) {
-    // the window a pass may stage: kTileTrips trips of the workgroup = 40 KiB, which with a 2048-entry chunk and
+    // the window a pass may stage: kTileTrips trips of the workgroup = 32 KiB, which with a 2048-entry chunk and
     // 2048 fp64 accumulators lets two workgroups share a CU's LDS, and with 8192 of them still fits one
     const int win_cols = kTileTrips * kTileTripBytes / (int)sizeof(T);
     plan = TilePlan<T>();

@@ -36,7 +36,7 @@ class tuned:
             set_tuning(k, v)
 
     def __exit__(self, *exc):
-        defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 16, "stream_kind": -1,
+        defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 4, "stream_kind": -1,
                     "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1, "tile_places": 0,
                     "tile_streams": 1, "tile_fit": 1}
         for k in self.kv:

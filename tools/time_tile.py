@@ -56,7 +56,7 @@ for w in want:  # uniform:<rows>:<per row>, band:<rows>:<per row>:<sigma>, web:<
     elif len(f) > 1 and f[0] == "web":
         CASES[w] = lambda f=f: synth.powerlaw(1 << int(f[1]), int(f[2]), 7)
 tile_rows = [int(v) for v in os.environ.get("TILE_ROWS", "2048").split(",")]
-dens = [int(v) for v in os.environ.get("TILE_DENSITY", "16").split(",")]
+dens = [int(v) for v in os.environ.get("TILE_DENSITY", "4").split(",")]
 chunks = [2048]
 sp.hip_init(0)
 for name in want:
@@ -106,4 +106,4 @@ for name in want:
                       f"diff_vs_gather={err:.1e}", flush=True)
     set_tuning("stream_tile", -1)
     set_tuning("tile_rows", 0)
-    set_tuning("tile_density", 16)
+    set_tuning("tile_density", 4)
