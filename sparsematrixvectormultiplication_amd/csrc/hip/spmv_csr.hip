@@ -194,6 +194,12 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.packed = want_pack && !tb.scattered;
+    // Mid-size matrices (fewer rows than kTileMinRows, but entries for four full passes on every place): only a
+    // band of dense rows pays -- the packed plan, with blocks thin enough to give every place one (their slices stay
+    // small next to their entries: 33 per row, 503 625 rows: 48.6 us in 493 blocks of 1024 rows against 68.3 us for the
+    // gather kernel and 59.5 us in 247 blocks of 2048; 50 per row, 161 070 rows: 30.8 against 39.9 us).
+    const bool mid = g_stream_tile < 0 && (long long)Ml < kTileMinRows;
+    if (mid && !tb.packed) return;
     // (auto) tile plans pay from about 800 000 rows / columns on (kTileMinRows, kTileGatherMinCols): 5 uniformly random
     // columns per row tie with the gather kernel at 750 000 rows (37.4 vs 37.9 us) and lose at 500 000 (28 vs 23 us); at
     // 1.09 M rows 3 per row win 37 vs 44 us, power-law fp32 74 vs 107 us, a road-like band 24 vs 29 us.  (Before the block
@@ -214,7 +220,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         const long long full = std::max(1, (Ml + rb - 1) / rb);
         const int b0 = (int)tile_cut_rows(Ml, row_len, g_tile_lmax, rb, std::max<long long>(chunk, (in_tiles + full - 1) / full)).size() - 1;
         // (a matrix whose blocks fill less than 90 % of one round keeps them: thinner blocks would each read more of x)
-        const int kmax = b0 * 10LL > places * 9LL ? (b0 + places - 1) / places : 0;
+        const int kmax = mid ? 1 : b0 * 10LL > places * 9LL ? (b0 + places - 1) / places : 0;
         for (int k = 1; k <= kmax; ++k) {
             const long long want = (long long)k * places * 197 / 200;
             const long long t = std::max<long long>(chunk, (in_tiles + want - 1) / want);
@@ -609,7 +615,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     // pieces cut at column stripes.
     TileBuild<T> tb;
     if (!have_local && nz > 0 && g_stream_tile != 0 && g_stream_cap == 0 &&
-        (g_stream_tile == 1 || (long long)Ml >= kTileMinRows)) {
+        (g_stream_tile == 1 || (long long)Ml >= kTileMinRows || nz >= kTileMidEntries)) {
         std::vector<int> col_copy;
         std::vector<T> val_copy;
         const int *hcol = col_idx ? col_idx + e0 : nullptr;

@@ -48,6 +48,7 @@ extern int g_pipe_wgs_per_cu; // resident workgroups per CU the persistent grids
 extern int g_stream_tile;     // csr_tile plan at upload: -1 = auto (no x-window plan, enough rows), 0 = never, 1 = whenever no x-window plan
 extern int g_tile_rows;       // rows per block: 0 = auto, else a power of two in 256..8192
 extern int g_tile_lmax;       // rows longer than this stay with the split-row kernels
+constexpr long long kTileMidEntries = 4LL << 20;  // (auto) ... or, for a band of dense rows, entries from which it gets one (packed plans only)
 constexpr long long kTileMinRows = 800000;  // (auto) rows from which a handle without an x-window plan gets a tile plan
 extern int g_tile_places;     // 0: the chip's (2 or 1 workgroups per CU) | the number of workgroup places the streams / the block count are made for
 extern int g_tile_items;      // work items the long rows' passes are dealt out to (about)
