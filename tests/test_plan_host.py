@@ -217,11 +217,21 @@ def test_tile_auto_plan_decisions():
         assert sc["tiles"] and not sc["packed"] and sc["scattered"] and sc["tallest_block"] <= sc["rows_per_block"] <= 16128
         rounds = -(-sc["blocks"] // 16)
         assert sc["blocks"] <= rounds * 16
-        # auto: scattered columns get tiles only from 800 000 columns on, whatever the rows
+        # auto: scattered columns get tiles from 800 000 rows and columns on ...
         set_tuning("stream_tile", -1)
-        assert sp.csr_tile_auto_plan(M, N, rp, col, 8)["tiles"] == 1
-        rp2, col2 = _scattered(rng, M, 600_000, 6)
+        assert sp.csr_tile_auto_plan(M, N, rp, col, 8)["tiles"] == 0      # 200 000 rows
+        M = 900_000
+        rp2, col2 = _scattered(rng, M, 900_000, 3)
+        big = sp.csr_tile_auto_plan(M, 900_000, rp2, col2, 8)
+        assert big["tiles"] == 1 and not big["packed"]
+        rp2, col2 = _scattered(rng, M, 600_000, 3)
         assert sp.csr_tile_auto_plan(M, 600_000, rp2, col2, 8)["tiles"] == 0
+        # ... a band of dense rows already from 4 Mi entries on: packed, one thin block per place
+        M = N = 80_000
+        rp3, col3 = _scattered(rng, M, N, 60, sigma=700)
+        mid = sp.csr_tile_auto_plan(M, N, rp3, col3, 8)
+        assert mid["tiles"] == 1 and mid["packed"] and 14 <= mid["blocks"] <= 16 and mid["tallest_block"] < 0.1 * M, mid
+
     finally:
         for k, v in (("tile_places", 0), ("stream_tile", -1), ("tile_fit", 1), ("tile_streams", 1)):
             set_tuning(k, v)
