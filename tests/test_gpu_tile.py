@@ -299,9 +299,10 @@ def test_tile_kernel_random_shapes(gpu, oracle):
     multiple of 4 (the last window piece ends inside a 16-byte piece), bands at the matrix edges, stray entries,
     empty rows, rows longer than a pass, both kinds of plan, fp64 and fp32 -- every case against the oracle, with y
     poisoned first and the launch repeated (bit-reproducible)."""
-    rng = np.random.default_rng(20260)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("TILE_FUZZ_SEED", "20260")))  # (other seeds / more cases: by hand)
     packed_seen = plain_seen = 0
-    for case in range(64):
+    for case in range(int(os.environ.get("TILE_FUZZ_CASES", "64"))):
         dtype = np.float64 if case % 3 else np.float32
         M = int(rng.integers(1, 30_000))
         N = int(rng.integers(1, 200_000)) if case % 4 else M
