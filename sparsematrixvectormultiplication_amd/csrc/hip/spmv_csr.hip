@@ -1063,7 +1063,7 @@ int csr_tiles_from_rows_f64(int M_local, int M_total, int row0, int N, const int
                             long long entries, const int *col, const double *val, spmv_csr_dev **out) {
     *out = nullptr;
     if (M_local <= 0 || entries <= 0 || g_stream_tile == 0) return 0;
-    if (g_stream_tile < 0 && (long long)M_local < kTileMinRows) return 0;
+    if (g_stream_tile < 0 && (long long)M_local < kTileMinRows && entries < kTileMidEntries) return 0;
     return guarded("hll tile plan", [&] {
         TileBuild<double> tb;
         tile_plan_all<double>(M_local, N, row_begin, row_len, nullptr, entries, col, val, tb);

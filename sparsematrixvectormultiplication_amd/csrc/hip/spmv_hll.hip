@@ -536,7 +536,7 @@ static int spmv_hip_hll_from_csr_body(const spmv_csr_dev *csr, spmv_hll_dev **ou
             e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
             // (the values too: a slab without an x-window plan may get the tile plan, built on the host)
-            if (g_stream_tile != 0 && (g_stream_tile == 1 || (long long)M >= kTileMinRows)) {
+            if (g_stream_tile != 0 && (g_stream_tile == 1 || (long long)M >= kTileMinRows || S >= kTileMidEntries)) {
                 as_host.resize((size_t)S);
                 e = hipMemcpy(as_host.data(), m->AS, (size_t)S * sizeof(double), hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { rc = fail("hll_from_csr: AS download failed: %s", hipGetErrorString(e)); break; }
