@@ -99,6 +99,7 @@ typedef struct {
     int tile_long_items;           /* CSR: workgroups of that plan */
     long long tile_long_entries;   /* CSR: entries it holds */
     long long tile_staged_cols;    /* CSR: x values the staged passes copy to LDS per SpMV (all tile plans): traffic served by L2 */
+    long long tile_remainder_entries; /* CSR: ... of tile_entries, in windows too sparse for a pass: added to y by tile_remainder behind the tiles */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -136,6 +137,8 @@ int spmv_hip_flush_cache(size_t bytes);
  *                     "tile_streams" 1 | 0 one csr_tile workgroup per place of the chip walks several row blocks back to
  *                     back (0: one workgroup per block); "tile_places" 0 (the chip's: 2 or 1 per CU) | a multiple of 8: how
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
+ *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
+ *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
  *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 32 KiB window and
  *                     staged, keys in the column words, kernel instantiation without gather code) unless its passes
  *                     would average fewer than 256 entries; 0: always the plan with gather passes

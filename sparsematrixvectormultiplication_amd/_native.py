@@ -54,7 +54,7 @@ class DevInfo(C.Structure):
                 ("tile_blocks", C.c_int), ("tile_passes", C.c_int), ("tile_split_rows", C.c_int),
                 ("tile_entries", C.c_longlong), ("tile_staged_entries", C.c_longlong),
                 ("tile_long_rows", C.c_int), ("tile_long_items", C.c_int), ("tile_long_entries", C.c_longlong),
-                ("tile_staged_cols", C.c_longlong)]
+                ("tile_staged_cols", C.c_longlong), ("tile_remainder_entries", C.c_longlong)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

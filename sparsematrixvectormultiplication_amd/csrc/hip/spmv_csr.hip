@@ -233,7 +233,11 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
-                                  g_tile_balance != 0, 17, tb.tiles, tb.packed, target);
+                                  g_tile_balance != 0, 17, tb.tiles, tb.packed, target, g_tile_min_pass);
+    // (the remainder is for a few per cent of far-out entries: more than 4 % and the plan is rebuilt without one)
+    if (tb.have_tiles && tb.packed && (long long)tb.tiles.rem_row.size() * 25 > tb.tiles.entries)
+        tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
+                                      g_tile_balance != 0, 17, tb.tiles, tb.packed, target, 0);
     // (the whole matrix may differ from the sample)
     if (tb.have_tiles && tb.packed && !pack_pays(tb.tiles)) {
         tb.packed = false;
@@ -294,6 +298,25 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
         rc |= upload_array(&m->tile_block_pass, tiles.stream_pass.data(), tiles.stream_pass.size(), 1);
         if (!rc) rc |= upload_array(&m->tile_block_row, tiles.block_row.data(), tiles.block_row.size(), 1);
         if (!rc) rc |= upload_array(&m->tile_pass, tiles.spass.data(), tiles.spass.size(), 1);
+        if (!rc && !tiles.rem_row.empty()) {  // remainder: rows that have any, their entry ranges
+            std::vector<int> rrow, rptr;
+            for (size_t k = 0; k < tiles.rem_row.size(); ++k) {
+                if (rrow.empty() || rrow.back() != tiles.rem_row[k]) {
+                    rrow.push_back(tiles.rem_row[k]);
+                    rptr.push_back((int)k);
+                }
+            }
+            rptr.push_back((int)tiles.rem_row.size());
+            rc |= upload_array(&m->tile_rem_row, rrow.data(), rrow.size(), 0);
+            if (!rc) rc |= upload_array(&m->tile_rem_ptr, rptr.data(), rptr.size(), 0);
+            if (!rc) rc |= upload_array(&m->tile_rem_col, tiles.rem_col.data(), tiles.rem_col.size(), 0);
+            if (!rc) rc |= upload_array((T **)&m->tile_rem_val, tiles.rem_val.data(), tiles.rem_val.size(), 0);
+            if (!rc) {
+                m->tile_rem_rows = (int)rrow.size();
+                m->tile_rem_entries = (long long)tiles.rem_row.size();
+                m->device_bytes += rrow.size() * 8 + tiles.rem_row.size() * (4 + sizeof(T));
+            }
+        }
         if (!rc) rc |= upload_array(&m->tile_stream_block, tiles.stream_block.data(), tiles.stream_block.size(), 1);
         if (!rc) rc |= upload_array(&m->tile_sblock_rows, tiles.sblock_rows.data(), tiles.sblock_rows.size(), 1);
         if (!rc) rc |= upload_array(&m->tcol, tiles.tcol.data(), tiles.tcol.size(), 0);
@@ -850,8 +873,20 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
     TilePlan<T> plan;
     std::vector<int> row_len((size_t)M);
     for (int r = 0; r < M; ++r) row_len[(size_t)r] = rp[r + 1] - rp[r];
-    if (!tile_build<T>(M, N, rp, row_len.data(), col, val.data(), rows_per_block, lmax, density, chunk, balance != 0, 17, plan, pack))
+    if (!tile_build<T>(M, N, rp, row_len.data(), col, val.data(), rows_per_block, lmax, density, chunk, balance != 0, 17, plan, pack, 0, pack ? 256 : 0))
         return fail("tile_plan_check: the plan does not fit 32-bit entry offsets");
+    // the remainder (packed plans: entries of windows too sparse for a pass): by (row, column), rows of the tiles only
+    std::vector<unsigned long long> rem_sum((size_t)M, 0ull);
+    if (plan.rem_row.size() != plan.rem_col.size() || plan.rem_row.size() != plan.rem_val.size() || (!pack && !plan.rem_row.empty()))
+        return fail("tile_plan_check: remainder arrays disagree");
+    for (size_t k = 0; k < plan.rem_row.size(); ++k) {
+        const int r = plan.rem_row[k], c = plan.rem_col[k];
+        if ((unsigned)r >= (unsigned)M || (unsigned)c >= (unsigned)N || plan.split[(size_t)r])
+            return fail("tile_plan_check: remainder entry %zu is out of range", k);
+        if (k > 0 && (plan.rem_row[k - 1] > r || (plan.rem_row[k - 1] == r && plan.rem_col[k - 1] > c)))
+            return fail("tile_plan_check: the remainder is not ordered by (row, column)");
+        rem_sum[(size_t)r] += (unsigned long long)(c + 1) * 0x9E3779B97F4A7C15ull + (unsigned long long)(double)plan.rem_val[k];
+    }
     const int win_cols = plan.win_cols;
     auto h = [](long long c, double v) { return (unsigned long long)(c + 1) * 0x9E3779B97F4A7C15ull + (unsigned long long)v; };
     if ((int)plan.block_pass.size() != plan.num_blocks + 1 || plan.block_pass.back() != (int)plan.pass_desc.size() ||
@@ -910,7 +945,7 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
             unsigned long long want = 0;
             if (!plan.split[(size_t)r0 + i])
                 for (int e = rp[r0 + i]; e < rp[r0 + i + 1]; ++e) want += h(col[e], (double)val[(size_t)e]);
-            if (acc[(size_t)i] != want) return fail("tile_plan_check: row %d does not add up through the tiles", r0 + i);
+            if (acc[(size_t)i] + rem_sum[(size_t)r0 + i] != want) return fail("tile_plan_check: row %d does not add up through the tiles", r0 + i);
         }
     }
     if (seen_entries != plan.entries) return fail("tile_plan_check: entry count disagrees");
@@ -972,11 +1007,11 @@ static int tile_plan_check(int M, int N, const int *rp, const int *col, int rows
     }
     for (int r = 0; r < M; ++r) n_split -= plan.split[(size_t)r];
     if (n_split != 0) return fail("tile_plan_check: split rows and piece lists disagree");
-    if (split_entries + plan.entries != nz) return fail("tile_plan_check: tiles + split rows do not hold every entry");
+    if (split_entries + plan.entries + (long long)plan.rem_row.size() != nz) return fail("tile_plan_check: tiles + remainder + split rows do not hold every entry");
     if (stats) {
         stats[0] = plan.num_blocks;
         stats[1] = (long long)plan.pass_desc.size();
-        stats[2] = plan.entries;
+        stats[2] = plan.entries + (long long)plan.rem_row.size();  // (packed: the remainder counts as held, not as staged)
         stats[3] = plan.staged_entries;
         stats[4] = (long long)long_rows.size();
         stats[5] = plan.max_win;
@@ -1128,6 +1163,10 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->tile_block_pass);
     (void)hipFree(m->tile_block_row);
     (void)hipFree(m->tile_pass);
+    (void)hipFree(m->tile_rem_row);
+    (void)hipFree(m->tile_rem_ptr);
+    (void)hipFree(m->tile_rem_col);
+    (void)hipFree(m->tile_rem_val);
     (void)hipFree(m->tile_stream_block);
     (void)hipFree(m->tile_sblock_rows);
     (void)hipFree(m->tcol);
@@ -1165,7 +1204,8 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->local_lines = m->local_lines;
     out->tile_blocks = m->tile_blocks;
     out->tile_passes = m->tile_passes;
-    out->tile_entries = m->tile_entries;
+    out->tile_entries = m->tile_entries + m->tile_rem_entries;
+    out->tile_remainder_entries = m->tile_rem_entries;
     out->tile_staged_entries = m->tile_staged;
     out->tile_split_rows = m->tile_num_long;
     out->tile_long_rows = m->lt.rows;
@@ -1290,6 +1330,9 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     if (m->tile_packed) { if (which) SPMV_TILE(true, true); else SPMV_TILE(false, true); }
                     else { if (which) SPMV_TILE(true, false); else SPMV_TILE(false, false); }
 #undef SPMV_TILE
+                    if (m->tile_rem_rows > 0)  // what the packed plan left out: added behind the tiles
+                        hipLaunchKernelGGL((tile_remainder<T>), dim3((m->tile_rem_rows + 255) / 256), dim3(256), 0, s, m->tile_rem_rows,
+                                           m->tile_rem_row, m->tile_rem_ptr, m->tile_rem_col, (const T *)m->tile_rem_val, x, y);
                     if (m->lt.items > 0) {
                         // the long rows' own tiles: work items -> slabs -> y (after the ordinary tiles wrote 0 there)
                         const auto &L = m->lt;

@@ -49,6 +49,7 @@ int g_skew_rows = 1;
 int g_tile_fit = 1;
 int g_tile_streams = 1;
 int g_tile_places = 0;
+int g_tile_min_pass = 256;
 int g_tile_items = 1008;  // two rounds of the 512 places: 1.222 ms on the power-law matrix against 1.248 with 4096, 1.231 with 504
 int g_tile_pack = 1;
 int g_tile_long = 1;
@@ -185,6 +186,9 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_tile_long = value;
     } else if (!strcmp(key, "tile_balance")) {
         g_tile_balance = value != 0;
+    } else if (!strcmp(key, "tile_min_pass")) {
+        if (value < 0 || value > 2048) return fail("set_tuning: tile_min_pass must be 0 (no remainder) .. 2048");
+        g_tile_min_pass = value;
     } else if (!strcmp(key, "tile_places")) {
         if (value < 0 || (value & 7) || value > 4096) return fail("set_tuning: tile_places must be 0 (the chip's) or a multiple of 8 up to 4096");
         g_tile_places = value;

@@ -623,6 +623,7 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
             out->tile_long_items = t.tile_long_items;
             out->tile_long_entries = t.tile_long_entries;
             out->tile_staged_cols = t.tile_staged_cols;
+            out->tile_remainder_entries = t.tile_remainder_entries;
             out->stream_bytes = t.stream_bytes + 12LL * m->hacks;
         }
     }

@@ -50,6 +50,7 @@ extern int g_tile_rows;       // rows per block: 0 = auto, else a power of two i
 extern int g_tile_lmax;       // rows longer than this stay with the split-row kernels
 constexpr long long kTileMidEntries = 4LL << 20;  // (auto) ... or, for a band of dense rows, entries from which it gets one (packed plans only)
 constexpr long long kTileMinRows = 800000;  // (auto) rows from which a handle without an x-window plan gets a tile plan
+extern int g_tile_min_pass;   // windows of a packed plan with fewer entries than this (and sparser than 1 per 16 columns) go to the remainder; 0: none
 extern int g_tile_places;     // 0: the chip's (2 or 1 workgroups per CU) | the number of workgroup places the streams / the block count are made for
 extern int g_tile_items;      // work items the long rows' passes are dealt out to (about)
 extern int g_tile_streams;    // 1: one csr_tile workgroup per place of the chip walks several row blocks back to back
@@ -159,6 +160,10 @@ struct spmv_csr_dev {
     int *tile_block_row = nullptr;    // [tile_blocks + 1] first row of every block
     int *tile_block_pass = nullptr;   // [tile_blocks + 1]
     int4 *tile_pass = nullptr;        // [tile_passes] in stream order
+    int tile_rem_rows = 0;            // rows with remainder entries (windows too sparse for a pass), tile_remainder
+    long long tile_rem_entries = 0;
+    int *tile_rem_row = nullptr, *tile_rem_ptr = nullptr, *tile_rem_col = nullptr;  // [rows], [rows + 1], [entries]
+    void *tile_rem_val = nullptr;
     int tile_streams = 0;             // workgroups of the csr_tile launch: each walks the blocks of one stream
     int *tile_stream_block = nullptr; // [tile_streams + 1] first block (in tile_sblock_rows) of every stream
     int2 *tile_sblock_rows = nullptr; // [tile_blocks] {first row, rows} in stream order

@@ -506,6 +506,19 @@ __global__ __launch_bounds__(kFinishRows *kFinishGroups) void tile_slab_finish(
         y[row_map[v]] = total;
     }
 }
+// The remainder of a packed plan: the entries of windows too sparse for a pass (tile_plan.hpp), one lane per row that has
+// any -- its few products in (row, column) order added to what the tiles left in y.  One owner per row, launched behind
+// the tiles on the same stream: the same bits every time.
+template <typename T>
+__global__ __launch_bounds__(256) void tile_remainder(int rows, const int *__restrict__ rrow, const int *__restrict__ rptr,
+                                                      const int *__restrict__ rcol, const T *__restrict__ rval,
+                                                      const T *__restrict__ x, T *__restrict__ y) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= rows) return;
+    T s = T(0);
+    for (int e = rptr[k]; e < rptr[k + 1]; ++e) s += rval[e] * x[rcol[e]];
+    y[rrow[k]] += s;
+}
 #undef SPMV_TILE_ENTRY_REGS
 #undef SPMV_TILE_ENTRY_ARGS
 

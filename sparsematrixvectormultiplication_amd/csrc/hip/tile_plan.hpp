@@ -48,6 +48,10 @@ struct TilePlan {
     std::vector<unsigned short> tkey;  // (a packed plan: padding only)
     std::vector<T> tval;
     std::vector<unsigned char> split;  // [M] 1: row is not in the tiles (longer than lmax)
+    // remainder (packed plans built with min_pass > 0): the entries of windows too sparse to be worth a pass -- the far
+    // tails of a band, stray entries -- by (row, column); added to y behind the tiles by tile_remainder
+    std::vector<int> rem_row, rem_col;  // row in the plan's row space, column
+    std::vector<T> rem_val;
     // streams (tile_make_streams): what ONE workgroup walks -- the passes of its blocks back to back, so that the
     // loads of a block's first passes go out while the block before it is still being summed
     int num_streams = 0;
@@ -69,6 +73,8 @@ struct Part {  // what one builder thread produced for its range of blocks
     long long entries = 0, staged_entries = 0, staged_cols = 0;
     int max_win = 0;
     bool failed = false;
+    std::vector<int> rem_row, rem_col;
+    std::vector<T> rem_val;
 };
 
 // std::sort of 64-bit keys whose top 32 bits are < key_top, with several threads: bucket by the leading bits
@@ -102,12 +108,18 @@ inline void sort_keys(std::vector<uint64_t> &keys, uint32_t key_top, int threads
 template <typename T>
 void build_range(int b0, int b1, const int *block_row, const int *row_begin, const int *row_len, const int *col,
                  const T *val, int lmax, int pos_bits, int chunk, int win_cols, int density, int inner_threads,
-                 uint32_t col_top, bool pack, Part<T> &out) {
+                 uint32_t col_top, bool pack, int min_pass, Part<T> &out) {
     // column << 32 | local row << pos_bits | position inside the row (rows <= lmax < 2^pos_bits, local rows < 2^(32 - pos_bits))
     std::vector<uint64_t> keyed;
     const uint32_t pos_mask = (1u << pos_bits) - 1;
     std::vector<uint64_t> pass;
+    struct Stray {
+        int row, col;
+        T val;
+    };
+    std::vector<Stray> rem;
     for (int b = b0; b < b1; ++b) {
+        rem.clear();
         const int r0 = block_row[b], r1 = block_row[b + 1];
         keyed.clear();
         for (int r = r0; r < r1; ++r) {
@@ -145,6 +157,17 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
                 const size_t cap = std::min(n, i + (size_t)chunk);
                 while (w < cap && (long long)(keyed[w] >> 32) < base + win_cols) ++w;
                 const long long span = (long long)(keyed[w - 1] >> 32) - base + 1;
+                if (pack && (int)(w - i) < min_pass && (long long)(w - i) * 16 < span) {
+                    // a window with a handful of entries far apart (the far tail of a band, stray entries): not worth
+                    // a pass -- a slice of x, two barriers -- of its own: to the remainder
+                    for (size_t k = i; k < w; ++k) {
+                        const int lrow = (int)((uint32_t)keyed[k] >> pos_bits), pos = (int)((uint32_t)keyed[k] & pos_mask);
+                        const int e = row_begin[r0 + lrow] + pos;
+                        rem.push_back(Stray{r0 + lrow, col[e], val[e]});
+                    }
+                    i = w;
+                    continue;
+                }
                 if (pack || (long long)(w - i) * density >= span) j = w;  // dense enough (pack: always): a staged pass
                 else j = cap;                                             // sparse here: a full gather pass
             }
@@ -200,6 +223,14 @@ void build_range(int b0, int b1, const int *block_row, const int *row_begin, con
             ++passes;
             i = j;
         }
+        if (!rem.empty()) {  // by (row, column): the remainder kernel adds a row's entries in that order
+            std::stable_sort(rem.begin(), rem.end(), [](const Stray &a, const Stray &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; });
+            for (const Stray &st : rem) {
+                out.rem_row.push_back(st.row);
+                out.rem_col.push_back(st.col);
+                out.rem_val.push_back(st.val);
+            }
+        }
         if (passes == 0) {  // a block without entries (empty rows, or only rows beyond the limit): one pass of none, so
             out.pass_desc.push_back(int4{(int)out.tcol.size(), 0, 0, pack ? ((16 / (int)sizeof(T)) | kTilePassPacked) : 0});  // that whoever
             passes = 1;                                                                           // walks it writes its zeros
@@ -232,7 +263,7 @@ inline std::vector<int> tile_cut_rows(int M, const int *row_len, int lmax, int r
 template <typename T>
 bool tile_build(int M, int N, const int *row_begin, const int *row_len, const int *col, const T *val, int rows_per_block,
                 int lmax, int density, int chunk, bool balance, int pos_bits, TilePlan<T> &plan, bool pack = true,
-                long long target_entries = 0) {
+                long long target_entries = 0, int min_pass = 0) {
     // the window a pass may stage: kTileTrips trips of the workgroup = 32 KiB, which with a 2048-entry chunk and
     // 2048 fp64 accumulators lets two workgroups share a CU's LDS, and with 8192 of them still fits one
     const int win_cols = kTileTrips * kTileTripBytes / (int)sizeof(T);
@@ -275,7 +306,7 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
     for (int th = 0; th < threads; ++th)
         pool.emplace_back([&, th] {
             tile_detail::build_range<T>(cut[th], cut[th + 1], plan.block_row.data(), row_begin, row_len, col, val, lmax,
-                                        pos_bits, chunk, win_cols, density, inner_threads, (uint32_t)std::max(N, 1), pack, parts[th]);
+                                        pos_bits, chunk, win_cols, density, inner_threads, (uint32_t)std::max(N, 1), pack, pack ? min_pass : 0, parts[th]);
         });
     for (auto &th : pool) th.join();
     size_t total_entries = 0, total_passes = 0;
@@ -305,6 +336,9 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
         plan.staged_entries += p.staged_entries;
         plan.staged_cols += p.staged_cols;
         plan.max_win = std::max(plan.max_win, p.max_win);
+        plan.rem_row.insert(plan.rem_row.end(), p.rem_row.begin(), p.rem_row.end());
+        plan.rem_col.insert(plan.rem_col.end(), p.rem_col.begin(), p.rem_col.end());
+        plan.rem_val.insert(plan.rem_val.end(), p.rem_val.begin(), p.rem_val.end());
     }
     // the kernel loads whole units past a pass's end
     plan.tcol.insert(plan.tcol.end(), (size_t)kTileChunkMax, 0);

@@ -143,16 +143,18 @@ def test_tile_plan_on_scattered_banded_and_skewed_matrices(vb, rows_per_block, c
     assert st["entries"] == rp[-1] and st["split_rows"] == 0 and st["passes"] >= st["blocks"]
     # the packed plan of the same matrix (the check builds both kinds): every pass cut at the window and staged, which
     # on scattered columns means many more passes -- what upload's fallback rule looks at
-    assert st["packed_entries"] == st["packed_staged_entries"] == rp[-1] and st["packed_passes"] >= st["passes"]
-    assert 0 < st["packed_max_window"] <= 40960 // vb
+    # -- or, since windows with a handful of entries go to the remainder (held, not staged), almost no passes at all:
+    # what upload's fallback rule looks at
+    assert st["packed_entries"] == rp[-1] and st["packed_staged_entries"] < 0.5 * rp[-1]
+    assert 0 <= st["packed_max_window"] <= 32768 // vb
     if rows_per_block == 2048:
         assert st["passes"] > 2 * st["blocks"] and st["staged_entries"] == 0
-        assert st["packed_passes"] > 4 * st["passes"]
     # a band: passes get staged in LDS
     rp, col = _scattered(rng, 9000, 9000, 12, sigma=300)
     st = sp_check(9000, 9000, rp, col, vb, rows_per_block)
-    assert st["staged_entries"] > 0.9 * st["entries"] and 0 < st["max_window"] <= 40960 // vb
-    assert st["packed_entries"] == st["packed_staged_entries"] == st["entries"] and st["packed_passes"] < 2 * st["passes"] + 8
+    assert st["staged_entries"] > 0.9 * st["entries"] and 0 < st["max_window"] <= 32768 // vb
+    assert st["packed_entries"] == st["entries"] and 0.95 * st["entries"] <= st["packed_staged_entries"] <= st["entries"]
+    assert st["packed_passes"] < 2 * st["passes"] + 8
     # skewed row lengths: runs longer than a lane's share (sub-runs), rows beyond the limit (split)
     lens = np.minimum((1.08 / rng.random(5000)).astype(np.int64), 40000)
     lens[[7, 4100]] = [30000, 70]

@@ -82,6 +82,7 @@ for name in want:
             set_tuning("tile_fit", int(os.environ.get("TILE_FIT", "1")))
             set_tuning("tile_streams", int(os.environ.get("TILE_STREAMS", "1")))
             set_tuning("tile_items", int(os.environ.get("TILE_ITEMS", "1008")))
+            set_tuning("tile_min_pass", int(os.environ.get("TILE_MIN_PASS", "256")))
             set_tuning("tile_pack", dn_pack)
             set_tuning("tile_lmax", int(os.environ.get("TILE_LMAX", "1024")))
             set_tuning("stream_tile", 1)
@@ -102,7 +103,7 @@ for name in want:
                 print(f"   tile pack={dn_pack} rows={tr:5d} density={dn:3d}: {ms.mean() * 1e3:8.1f} us  {info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  "
                       f"{info['algo_bytes'] / ms.mean() / 1e6 / 80:5.1f} %  blocks={info['tile_blocks']} passes={info['tile_passes']} "
                       f"staged={info['tile_staged_entries'] / max(1, info['tile_entries']):.2f} window_MB={info['tile_staged_cols'] * val.itemsize / 1e6:.0f} split_rows={info['tile_split_rows']} "
-                      f"in_tiles={info['tile_entries'] / nnz:.2f} long_rows={info['tile_long_rows']} long_items={info['tile_long_items']} in_long={info['tile_long_entries'] / nnz:.2f} format_bytes={info['stream_bytes']} upload={up:.1f}s "
+                      f"in_tiles={info['tile_entries'] / nnz:.2f} long_rows={info['tile_long_rows']} long_items={info['tile_long_items']} in_long={info['tile_long_entries'] / nnz:.2f} remainder={info['tile_remainder_entries'] / nnz:.4f} format_bytes={info['stream_bytes']} upload={up:.1f}s "
                       f"diff_vs_gather={err:.1e}", flush=True)
     set_tuning("stream_tile", -1)
     set_tuning("tile_rows", 0)
