@@ -233,7 +233,9 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
         }
     }
     tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
-                                  g_tile_balance != 0, 17, tb.tiles, tb.packed, target, g_tile_min_pass);
+                                  g_tile_balance != 0, 17, tb.tiles, tb.packed, target,
+                                  // (its extra launch costs ~2 us: not for matrices whose whole product takes 25)
+                                  nz >= (16LL << 20) || g_stream_tile == 1 ? g_tile_min_pass : 0);
     // (the remainder is for a few per cent of far-out entries: more than 4 % and the plan is rebuilt without one)
     if (tb.have_tiles && tb.packed && (long long)tb.tiles.rem_row.size() * 25 > tb.tiles.entries)
         tb.have_tiles = tile_build<T>(Ml, N, row_begin, row_len, hcol, hval, rb, g_tile_lmax, density, chunk,
