@@ -1,5 +1,11 @@
-import sys, numpy as np
-sys.path.insert(0, ".")
+#!/usr/bin/env python3
+"""Does the headline kernel time drift over a long run (clock ramp, thermal)?  Three times the bench protocol (5 + 95 launches) and
+2000 launches in blocks of 200 on the nlpkkt120-like stand-in: 179.3-179.5 us throughout on the box it was run on."""
+import os
+import sys
+
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sparsematrixvectormultiplication_amd as sp
 from sparsematrixvectormultiplication_amd import synth
 sp.hip_init(0)
