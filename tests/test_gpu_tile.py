@@ -137,6 +137,8 @@ def test_tile_kernel_packed_plan_outliers_and_fallback(gpu, oracle, dtype, far, 
             assert packed == (far < 0.1), info
             if packed:
                 assert info["tile_staged_cols"] > 0
+            if far == 0.004:  # the stray entries sit in windows too sparse for a pass: the remainder kernel adds them
+                assert 0 < info["tile_remainder_entries"] <= 0.04 * rp[-1], info["tile_remainder_entries"]
             check(dev, x, y_ref, rp, col, val, dtype, f"packed={packed} far={far}")
             buf, ybuf = C.c_void_p(), C.c_void_p()
             assert L.spmv_hip_malloc(C.byref(buf), (N + 64) * item) == 0 and L.spmv_hip_malloc(C.byref(ybuf), M * item) == 0
