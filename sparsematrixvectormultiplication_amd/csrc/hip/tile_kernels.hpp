@@ -9,8 +9,9 @@
 // restructures the product in two dimensions instead of one:
 //
 //   * rows are cut into ROW BLOCKS of consecutive rows (at most `rows_per_block`, about equally many
-//     entries each); one workgroup owns a block and keeps its y values as accumulators in LDS for the
-//     whole kernel;
+//     entries each, as many blocks as fill whole rounds of the workgroups the chip holds at once); a workgroup
+//     keeps a block's y values as accumulators in LDS while it walks the block's passes, and walks several
+//     blocks back to back (a STREAM: the next block's first loads are in flight while this one is summed);
 //   * the block's entries are re-ordered at upload into PASSES = consecutive column ranges of at most 2048
 //     entries, and inside a pass by (row, column).  All workgroups start at column 0 and sweep upwards
 //     together -- equal work per block keeps them in step -- so at any moment the chip gathers from a
@@ -21,8 +22,11 @@
 //   * a pass whose column range is narrow and dense enough is STAGED: its slice of x is copied into
 //     LDS with full-width coalesced loads and the per-entry lookups become ds_reads (the x-window
 //     idea with a dense window instead of a line list);
+//     a banded matrix gets a PACKED plan: every pass is cut at the slice's width and staged (entries of
+//     almost empty windows go to a remainder that tile_remainder adds behind the tiles), and the kernel
+//     instantiation for it has no gather code and sends out the same loads in every pass;
 //   * inside a pass an entry carries a key {head flag, local row} -- 16 bits beside a 32-bit column, or,
-//     in a pass that can be staged, packed with the column's offset in the slice into one 32-bit word --
+//     in a packed plan, packed with the column's offset in the slice into one 32-bit word --
 //     and every lane holds FOUR CONSECUTIVE entries, so most of a row's run is added up in registers:
 //     runs that begin and end inside a lane go straight to the accumulator; a run that crosses lanes is
 //     finished by a right-to-left segmented scan over the lanes' leading partial sums (DPP row shifts and
@@ -51,8 +55,8 @@ constexpr int kTileChunkMax = 4096;  // padding behind the entry arrays (the pla
 constexpr int kTileRowsMax = 16384;  // rows per block at most (local row fits the key's 14 bits)
 constexpr int kTileHead = 0x8000;    // key bit: first entry of its row in this pass
 constexpr int kTileRowMask = 0x3fff;
-// A pass that CAN be staged (pass_desc.w > 0) normally stores its entries PACKED (pass_desc.w bit 30): the column word holds
-// head << 31 | local row << 14 | (column - first staged column) and the key array is not read for it at all --
+// The passes of a PACKED plan (pass_desc.w bit 30; all of them or none) store their entries packed: the column word holds
+// head << 31 | local row << 14 | (column - first staged column) and there is no key array --
 // 4 + sizeof(T) bytes per entry, CSR's own, instead of 6 + sizeof(T).
 constexpr int kTilePassPacked = 1 << 30;  // pass_desc.w bit: the pass's entries are packed
 constexpr int kTilePassLast = 1 << 29;    // pass_desc.w bit (stream order only): the last pass of its block
