@@ -336,9 +336,10 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
     if (sblock_rows && live && (d.w & kTilePassLast)) {  // wave-uniform
         // a stream's block ends here: its rows go out, the accumulators start again at 0 for the next block, whose
         // first passes' loads are already on their way (the next accumulator update is behind the next pass's barrier)
-        // (the compiler drains the queue -- vmcnt(0) -- in front of this loop of stores: once per block, and what it
-        // waits for are the next block's first passes, which are needed next anyway; a fixed number of trips with each
-        // store under its own test instead made it spill and wait everywhere)
+        // (the queue is drained here once per block -- vmcnt(0): the block's rows come by a vector load, the youngest in the
+        // queue.  Fetching them a pass early by a scalar load removes the drain and buys nothing measurable -- road-like
+        // 132.7 -> 132.3 us, and 2 % lost on the plans with gather passes: what is waited for are the next block's first
+        // passes, which are needed next anyway.)
         __syncthreads();
         const int2 br = sblock_rows[bi++];
         for (int i = t; i < rows_per_block; i += kTileBlock) {
