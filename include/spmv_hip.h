@@ -114,6 +114,14 @@ int spmv_hip_device_name(char *buf, size_t len, int *compute_units, long long *h
  * (answers clear_gpu_cache / clear_cache_kernel, cuda_src/utility.cu:140-175;
  * the reference's 64 MiB is far below MI355X's 256 MiB Infinity Cache). */
 int spmv_hip_flush_cache(size_t bytes);
+/* Box state for bench records (round 3: the same code runs 180 or 200 us on the headline matrix depending on the box):
+ * "key=value;..." with pci (bus id, to find the card under /sys/class/drm), arch, cus, sclk_khz / mclk_khz (HIP clock
+ * attributes), mem_bus_bits, l2_bytes, hbm_bytes, xcds (from the chip's CU count: 32 per XCD).  Needs spmv_hip_init. */
+int spmv_hip_device_state(char *buf, size_t len);
+/* Read-only streaming probe: `iters` launches that each read `bytes` (a scratch buffer the library keeps) with 16-byte
+ * non-temporal loads, 2048-thread-blocks grid-stride; mean / min event time per launch in ms.  What this box's HBM
+ * gives a pure stream right now: the yardstick beside every kernel time in a bench line. */
+int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min);
 /* Kernel tuning knobs, for A/B measurements (defaults are the measured best; also settable through the
  * environment, SPMV_TUNING="key=value,...", read by spmv_hip_init):
  *   read at upload
@@ -204,6 +212,13 @@ int spmv_hip_csr_download(const spmv_csr_dev *m, int *row_ptr, int *col, void *v
 int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **out);
 void spmv_hip_csr_free(spmv_csr_dev *m);
 int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out);
+/* device addresses of the handle's arrays (placement studies): out[8] = row_ptr, col, val, x, y, lcol, lines, ldesc4
+ * (0 where the handle has none) */
+int spmv_hip_csr_addresses(const spmv_csr_dev *m, unsigned long long *out);
+/* Move one array of the handle (same numbering) to an address of the form (multiple of `align`) + offset; align a
+ * power of two >= 256, offset a multiple of 256 below it.  Round 3 found the x-window kernel's time on the headline
+ * matrix to depend on where its arrays lie (profiles/r3_placement_*.txt); this is the tool that study used. */
+int spmv_hip_csr_relocate(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset);
 
 /* library-owned vectors: host -> x, run, y -> host (y has M_total entries;
  * this handle writes rows [row0, row0 + M_local) of it) */

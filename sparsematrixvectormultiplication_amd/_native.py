@@ -145,6 +145,10 @@ _PROTOTYPES = {
     "spmv_hip_last_error": (C.c_char_p, []),
     "spmv_hip_device_name": (C.c_int, [C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_longlong)]),
     "spmv_hip_flush_cache": (C.c_int, [C.c_size_t]),
+    "spmv_hip_device_state": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "spmv_hip_stream_probe": (C.c_int, [C.c_size_t, C.c_int, C.c_int, c_float_p, c_float_p]),
+    "spmv_hip_csr_addresses": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "spmv_hip_csr_relocate": (C.c_int, [C.c_void_p, C.c_int, C.c_ulonglong, C.c_ulonglong]),
     "spmv_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "spmv_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "spmv_hip_free": (C.c_int, [C.c_void_p]),

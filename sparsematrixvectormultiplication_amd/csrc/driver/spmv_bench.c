@@ -199,21 +199,24 @@ static int bench_matrix(const char *path, const char *name, const char *out_dir,
         fclose(fp);
     }
     /* launch shapes (reference: write_block_result_to_csv, cuda_src/utility.cu:236-261, called at
-     * main_cuda.cu:728 with the occupancy API's threads per block).  Every kernel here runs 256-thread
-     * workgroups (4 wavefronts), so the kept schema gets that; what really differs per matrix -- lanes
-     * per row, stage, workgroups, kernel the fast path resolved to -- goes to a second file. */
+     * main_cuda.cu:728 with the occupancy API's threads per block).  The row / wave / sub-wave kernels and
+     * the x-window and gather stream kernels run 256-thread workgroups (4 wavefronts); csr_tile -- what the
+     * "shared" slot (STREAM / LDS) resolves to for matrices without an x-window plan -- runs 512 (8
+     * wavefronts).  What really differs per matrix -- lanes per row, stage, workgroups, kernel the fast path
+     * resolved to -- goes to a second file. */
     snprintf(file, sizeof file, "%s/spmv_results_hip_block_dim.csv", out_dir);
-    write_block_result_to_csv(name, nz, 256, 256, 256, 256, 256, 256, file);
+    write_block_result_to_csv(name, nz, 256, 256, ci.stream_kernel == 3 ? 512 : 256, 256, 256,
+                              hi.stream_kernel == 2 ? 512 : 256, file);
     snprintf(file, sizeof file, "%s/spmv_results_hip_launch_shape.csv", out_dir);
     fp = fopen(file, "a+");
     if (fp) {
         fseek(fp, 0, SEEK_END);
         if (ftell(fp) == 0)
-            fputs("matrix_name,nonzeros,threads_per_workgroup,csr_lanes_per_row_subwave,csr_stream_kernel,"
+            fputs("matrix_name,nonzeros,threads_per_workgroup_stream_csr,csr_lanes_per_row_subwave,csr_stream_kernel,"
                   "csr_stream_workgroups,csr_xwindow_workgroups,csr_xwindow_stage_lines,csr_split_rows,"
                   "hll_lanes_per_row_subwave,hll_lds_kernel,hll_lds_workgroups,hll_xwindow_workgroups,"
                   "hll_xwindow_stage_lines\n", fp);
-        fprintf(fp, "%s,%d,256,%d,%s,%d,%d,%d,%d,%d,%s,%d,%d,%d\n", name, nz, ci.lanes_per_row,
+        fprintf(fp, "%s,%d,%d,%d,%s,%d,%d,%d,%d,%d,%s,%d,%d,%d\n", name, nz, ci.stream_kernel == 3 ? 512 : 256, ci.lanes_per_row,
                 ci.stream_kernel == 1 ? "csr_stream_local" : (ci.stream_kernel == 2 ? "csr_stream_short" : (ci.stream_kernel == 3 ? "csr_tile" : "csr_stream")),
                 ci.stream_blocks, ci.local_blocks, ci.local_stage_lines, ci.long_rows, hi.lanes_per_row,
                 hi.stream_kernel == 1 ? "hll_lds_local" : (hi.stream_kernel == 2 ? "csr_tile(hll)" : "hll_lds"), hi.stream_blocks, hi.local_blocks,

@@ -148,15 +148,23 @@ int allgatherv_mode(void *d_y, const int *bounds, int value_bytes, hipStream_t s
     const ncclDataType_t dt = value_bytes == 8 ? ncclDouble : ncclFloat;
     if (mode == 0) {
         // RCCL has no all-gather-v: one broadcast per owner, fused into one group
-        // so the 7 peer copies of every slice go out over distinct xGMI links at once
+        // so the 7 peer copies of every slice go out over distinct xGMI links at once.
+        // An error inside the group still closes it: a group left open would swallow every later
+        // RCCL call of the process.
         NCCL_TRY(ncclGroupStart());
-        for (int r = 0; r < g_comm_size; ++r) {
+        ncclResult_t bad = ncclSuccess;
+        int bad_rank = -1;
+        for (int r = 0; r < g_comm_size && bad == ncclSuccess; ++r) {
             const size_t count = (size_t)(bounds[r + 1] - bounds[r]);
             if (!count) continue;
             char *slice = (char *)d_y + (size_t)bounds[r] * value_bytes;
-            NCCL_TRY(ncclBroadcast(slice, slice, count, dt, r, g_comm, s));
+            bad = ncclBroadcast(slice, slice, count, dt, r, g_comm, s);
+            if (bad != ncclSuccess) bad_rank = r;
         }
-        NCCL_TRY(ncclGroupEnd());
+        const ncclResult_t closed = ncclGroupEnd();
+        if (bad != ncclSuccess)
+            return fail("comm_allgatherv: ncclBroadcast(root %d) failed: %s", bad_rank, ncclGetErrorString(bad));
+        if (closed != ncclSuccess) return fail("comm_allgatherv: ncclGroupEnd failed: %s", ncclGetErrorString(closed));
         return 0;
     }
     // every slice padded to the widest one: a single in-place ncclAllGather over a staging
@@ -223,6 +231,32 @@ int poison_peer_slices(void *d_y, const int *bounds, int value_bytes, hipStream_
 // must equal the reference copy word for word (a mode that delivers nothing leaves poison behind).
 // Mode 0 failing that check is an error; mode 1 failing it is rejected (ms_modes[1] < 0).
 // Collective: every rank must call it with the same bounds.  y must hold a gathered vector already.
+//
+// No rank may skip a collective the others enter: everything that can fail on one rank alone (allocations,
+// the staging buffer of mode 1) happens BEFORE the first collective, and the ranks then agree -- one
+// all-reduce of a failure flag -- whether to go on; the same agreement closes every mode, so a rank
+// whose launches failed takes all ranks out together with an error instead of leaving them in a
+// collective it never joins.
+namespace {
+
+// Sum over the ranks of "this rank failed".  >0: some rank failed (all ranks see the same number);
+// -1: the agreement itself failed (then nothing more can be said to the peers).
+long long agree_failures(unsigned long long *d_flag, bool failed_here) {
+    const unsigned long long mine = failed_here ? 1 : 0;
+    unsigned long long all = 0;
+    hipError_t e = hipMemcpyAsync(d_flag, &mine, sizeof mine, hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);  // `mine` is pageable: the copy is done here
+    if (e != hipSuccess) return fail("comm_autotune: agreement copy failed: %s", hipGetErrorString(e));
+    const ncclResult_t n = ncclAllReduce(d_flag, d_flag, 1, ncclUint64, ncclSum, g_comm, g_stream);
+    if (n != ncclSuccess) return fail("comm_autotune: agreement all-reduce failed: %s", ncclGetErrorString(n));
+    e = hipStreamSynchronize(g_stream);
+    if (e == hipSuccess) e = hipMemcpy(&all, d_flag, sizeof all, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail("comm_autotune: agreement read-back failed: %s", hipGetErrorString(e));
+    return (long long)all;
+}
+
+}  // namespace
+
 extern "C" int spmv_hip_comm_autotune(void *d_y, const int *bounds, int value_bytes, int iters, int *mode_out,
                                       float *ms_modes) {
     if (need_device()) return -1;
@@ -233,51 +267,76 @@ extern "C" int spmv_hip_comm_autotune(void *d_y, const int *bounds, int value_by
     const size_t bytes = (size_t)bounds[g_comm_size] * value_bytes;
     void *copy = nullptr;
     float *d_ms = nullptr;
-    unsigned long long *d_bad = nullptr;  // [2]: mismatching words per mode
+    unsigned long long *d_bad = nullptr;  // [0..1]: mismatching words per mode, [2]: the agreement flag
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     float ms[2] = {0, 0};
     unsigned long long bad[2] = {0, 0};
+    // the agreement word first: without it this rank cannot even tell the others that it failed
+    if (hipMalloc((void **)&d_bad, 3 * sizeof *d_bad) != hipSuccess)
+        return fail("comm_autotune: cannot allocate the agreement word (no collective was entered)");
     do {
+        // ---- everything that can fail on this rank alone, before any collective
         hipError_t e = hipMalloc(&copy, std::max<size_t>(bytes, 16));
         if (e == hipSuccess) e = hipMalloc((void **)&d_ms, 2 * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_bad, 2 * sizeof *d_bad);
         if (e == hipSuccess) e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
-        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 2 * sizeof *d_bad, g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 3 * sizeof *d_bad, g_stream);
         if (e == hipSuccess) e = hipMemcpyAsync(copy, d_y, bytes, hipMemcpyDeviceToDevice, g_stream);  // the reference
-        if (e != hipSuccess) { rc = fail("comm_autotune: setup failed: %s", hipGetErrorString(e)); break; }
+        int local = 0;
+        if (e != hipSuccess) local = fail("comm_autotune: setup failed: %s", hipGetErrorString(e));
+        if (!local) local = ensure_stage((size_t)g_comm_size * (size_t)std::max<long long>(1, widest_slice(bounds, g_comm_size)) * value_bytes);
+        std::string first_error = local ? spmv_hip_last_error() : "";
+        long long failed = agree_failures(d_bad + 2, local != 0);
+        if (failed < 0) { rc = -1; break; }
+        if (failed > 0) {
+            rc = local ? fail("%s", first_error.c_str())
+                       : fail("comm_autotune: setup failed on %lld other rank(s); no mode was run", failed);
+            break;
+        }
         for (int mode = 0; mode < 2 && !rc; ++mode) {
-            // correctness from a poisoned vector
-            rc = poison_peer_slices(d_y, bounds, value_bytes, g_stream);
-            if (!rc) rc = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
-            if (rc) break;
-            if (bytes)
-                hipLaunchKernelGGL(count_word_mismatches, dim3(512), dim3(kBlock), 0, g_stream, (const unsigned *)copy,
-                                   (const unsigned *)d_y, (long long)(bytes / 4), d_bad + mode);
-            // whatever the mode did, timing (and the caller afterwards) works on the good vector
-            e = hipMemcpyAsync(d_y, copy, bytes, hipMemcpyDeviceToDevice, g_stream);
-            for (int i = 0; i < 2 && !rc; ++i) rc = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
-            if (rc) break;
-            if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
-            for (int i = 0; i < iters && !rc && e == hipSuccess; ++i)
-                rc = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
-            if (rc) break;
-            if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms[mode], e0, e1);
-            if (e != hipSuccess) rc = fail("comm_autotune: timing failed: %s", hipGetErrorString(e));
-            ms[mode] /= (float)iters;
+            local = 0;
+            do {
+                // correctness from a poisoned vector
+                local = poison_peer_slices(d_y, bounds, value_bytes, g_stream);
+                if (!local) local = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
+                if (local) break;
+                if (bytes)
+                    hipLaunchKernelGGL(count_word_mismatches, dim3(512), dim3(kBlock), 0, g_stream, (const unsigned *)copy,
+                                       (const unsigned *)d_y, (long long)(bytes / 4), d_bad + mode);
+                // whatever the mode did, timing (and the caller afterwards) works on the good vector
+                e = hipMemcpyAsync(d_y, copy, bytes, hipMemcpyDeviceToDevice, g_stream);
+                for (int i = 0; i < 2 && !local; ++i) local = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
+                if (local) break;
+                if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
+                for (int i = 0; i < iters && !local; ++i) local = allgatherv_mode(d_y, bounds, value_bytes, g_stream, mode);
+                if (local) break;
+                if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+                if (e == hipSuccess) e = hipEventElapsedTime(&ms[mode], e0, e1);
+                if (e != hipSuccess) local = fail("comm_autotune: timing failed: %s", hipGetErrorString(e));
+                ms[mode] /= (float)iters;
+            } while (0);
+            // every rank closes the mode with the same agreement, whatever happened to it
+            first_error = local ? spmv_hip_last_error() : "";
+            failed = agree_failures(d_bad + 2, local != 0);
+            if (failed < 0) rc = -1;
+            else if (failed > 0)
+                rc = local ? fail("%s", first_error.c_str())
+                           : fail("comm_autotune: mode %d failed on %lld other rank(s)", mode, failed);
         }
         if (rc) break;
         // leave y as it was handed in (a rejected mode may have run last)
         e = hipMemcpyAsync(d_y, copy, bytes, hipMemcpyDeviceToDevice, g_stream);
         // agree across ranks: slowest rank's time per mode, total mismatches per mode
         if (e == hipSuccess) e = hipMemcpyAsync(d_ms, ms, sizeof ms, hipMemcpyHostToDevice, g_stream);
-        if (e != hipSuccess) { rc = fail("comm_autotune: copy failed: %s", hipGetErrorString(e)); break; }
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        // (a failure here is local; the reductions below are still entered so that no peer waits alone)
+        const bool copy_failed = e != hipSuccess;
         ncclResult_t n = ncclAllReduce(d_ms, d_ms, 2, ncclFloat, ncclMax, g_comm, g_stream);
         if (n == ncclSuccess) n = ncclAllReduce(d_bad, d_bad, 2, ncclUint64, ncclSum, g_comm, g_stream);
         if (n != ncclSuccess) { rc = fail("comm_autotune: ncclAllReduce failed: %s", ncclGetErrorString(n)); break; }
+        if (copy_failed) { rc = fail("comm_autotune: copy failed: %s", hipGetErrorString(e)); break; }
         e = hipStreamSynchronize(g_stream);
         if (e == hipSuccess) e = hipMemcpy(ms, d_ms, sizeof ms, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
@@ -645,11 +704,18 @@ extern "C" int spmv_hip_comm_halo_exchange(void *d_vec, int value_bytes, void *s
     const ncclDataType_t dt = value_bytes == 8 ? ncclDouble : ncclFloat;
     if (g_halo_send.empty() && g_halo_recv.empty()) return 0;
     NCCL_TRY(ncclGroupStart());
-    for (const auto &g : g_halo_send)
-        NCCL_TRY(ncclSend((char *)d_vec + (size_t)g.lo * value_bytes, (size_t)(g.hi - g.lo), dt, g.peer, g_comm, s));
-    for (const auto &g : g_halo_recv)
-        NCCL_TRY(ncclRecv((char *)d_vec + (size_t)g.lo * value_bytes, (size_t)(g.hi - g.lo), dt, g.peer, g_comm, s));
-    NCCL_TRY(ncclGroupEnd());
+    ncclResult_t bad = ncclSuccess;  // an error inside the group still closes it (see allgatherv_mode)
+    for (size_t k = 0; k < g_halo_send.size() && bad == ncclSuccess; ++k) {
+        const auto &g = g_halo_send[k];
+        bad = ncclSend((char *)d_vec + (size_t)g.lo * value_bytes, (size_t)(g.hi - g.lo), dt, g.peer, g_comm, s);
+    }
+    for (size_t k = 0; k < g_halo_recv.size() && bad == ncclSuccess; ++k) {
+        const auto &g = g_halo_recv[k];
+        bad = ncclRecv((char *)d_vec + (size_t)g.lo * value_bytes, (size_t)(g.hi - g.lo), dt, g.peer, g_comm, s);
+    }
+    const ncclResult_t closed = ncclGroupEnd();
+    if (bad != ncclSuccess) return fail("comm_halo_exchange: ncclSend / ncclRecv failed: %s", ncclGetErrorString(bad));
+    if (closed != ncclSuccess) return fail("comm_halo_exchange: ncclGroupEnd failed: %s", ncclGetErrorString(closed));
     return 0;
 }
 

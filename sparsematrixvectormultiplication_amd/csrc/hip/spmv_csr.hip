@@ -1141,6 +1141,10 @@ extern "C" int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **o
 
 extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     if (!m) return;
+    for (auto &r : m->relocs) {  // relocated arrays: the field points into r.raw
+        *r.field = nullptr;
+        (void)hipFree(r.raw);
+    }
     (void)hipFree(m->row_ptr);
     (void)hipFree(m->col);
     (void)hipFree(m->val);
@@ -1182,6 +1186,51 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->x);
     (void)hipFree(m->y);
     delete m;
+}
+
+// Placement study / placement rule: move one array of the handle to an address of the form
+// (multiple of `align`) + offset.  which: 0 row_ptr, 1 col, 2 val, 3 x, 4 y, 5 lcol, 6 lines, 7 ldesc4.
+extern "C" int spmv_hip_csr_relocate(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset) {
+    if (need_device()) return -1;
+    if (!m || which < 0 || which > 7) return fail("csr_relocate: bad arguments");
+    if (align < 256 || (align & (align - 1)) || (offset & 255) || offset >= align)
+        return fail("csr_relocate: align must be a power of two >= 256, offset a multiple of 256 below it");
+    void **fields[8] = {(void **)&m->row_ptr, (void **)&m->col, &m->val, &m->x, &m->y, (void **)&m->lcol,
+                        (void **)&m->lines, (void **)&m->ldesc4};
+    void **field = fields[which];
+    if (!*field) return 0;  // the handle has no such array
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    size_t size = 0;
+    void *old_raw = *field;
+    size_t at = m->relocs.size();
+    for (size_t k = 0; k < m->relocs.size(); ++k)
+        if (m->relocs[k].field == field) at = k;
+    if (at < m->relocs.size()) {
+        size = m->relocs[at].size;
+        old_raw = m->relocs[at].raw;
+    } else {
+        HIP_TRY(hipMemPtrGetInfo(*field, &size));
+    }
+    void *raw = nullptr;
+    HIP_TRY(hipMalloc(&raw, size + align + offset));
+    char *p = (char *)(((uintptr_t)raw + align - 1) & ~(uintptr_t)(align - 1)) + offset;
+    hipError_t e = hipMemcpy(p, *field, size, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(raw);
+        return fail("csr_relocate: copy failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(old_raw);
+    *field = p;
+    if (at < m->relocs.size()) m->relocs[at] = {field, raw, size};
+    else m->relocs.push_back({field, raw, size});
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_addresses(const spmv_csr_dev *m, unsigned long long *out) {
+    if (!m || !out) return fail("csr_addresses: NULL argument");
+    const void *p[8] = {m->row_ptr, m->col, m->val, m->x, m->y, m->lcol, m->lines, m->ldesc4};
+    for (int i = 0; i < 8; ++i) out[i] = (unsigned long long)(uintptr_t)p[i];
+    return 0;
 }
 
 extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {

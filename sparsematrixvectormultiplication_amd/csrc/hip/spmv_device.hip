@@ -18,6 +18,23 @@ __global__ __launch_bounds__(kBlock) void flush_kernel(uint4 *__restrict__ buf, 
     }
 }
 
+// Read-only stream: every lane sums 16-byte non-temporal loads, one value per workgroup leaves the chip.
+__global__ __launch_bounds__(kBlock) void stream_probe_kernel(const uint4 *__restrict__ buf, size_t n,
+                                                              unsigned *__restrict__ sink) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u *p = reinterpret_cast<const v4u *>(buf);
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    unsigned acc = 0;
+    for (; i + 3 * stride < n; i += 4 * stride) {  // four loads in flight per lane
+        const v4u a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+        const v4u c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+        acc += a.x ^ b.y ^ c.z ^ d.w;
+    }
+    for (; i < n; i += stride) acc += __builtin_nontemporal_load(p + i).x;
+    if (acc == 0x9e3779b9u) sink[blockIdx.x] = acc;  // never true on the zeroed buffer: keeps the loads alive
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ state
@@ -264,6 +281,64 @@ extern "C" int spmv_hip_flush_cache(size_t bytes) {
                        bytes / 16);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int spmv_hip_device_state(char *buf, size_t len) {
+    if (need_device()) return -1;
+    if (!buf || !len) return fail("device_state: NULL buffer");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    char pci[32] = "";
+    (void)hipDeviceGetPCIBusId(pci, (int)sizeof pci, g_device);
+    int sclk = 0, mclk = 0, bus = 0, l2 = 0;
+    (void)hipDeviceGetAttribute(&sclk, hipDeviceAttributeClockRate, g_device);
+    (void)hipDeviceGetAttribute(&mclk, hipDeviceAttributeMemoryClockRate, g_device);
+    (void)hipDeviceGetAttribute(&bus, hipDeviceAttributeMemoryBusWidth, g_device);
+    (void)hipDeviceGetAttribute(&l2, hipDeviceAttributeL2CacheSize, g_device);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    snprintf(buf, len, "pci=%s;arch=%s;cus=%d;xcds=%d;sclk_khz=%d;mclk_khz=%d;mem_bus_bits=%d;l2_bytes=%d;"
+                       "hbm_bytes=%zu;hbm_free_bytes=%zu",
+             pci, prop.gcnArchName, prop.multiProcessorCount, prop.multiProcessorCount / 32, sclk, mclk, bus, l2,
+             total_b, free_b);
+    return 0;
+}
+
+extern "C" int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min) {
+    if (need_device()) return -1;
+    if (iters <= 0 || iters > 1000 || warmup < 0) return fail("stream_probe: iters must be 1..1000");
+    if (bytes < (1u << 20)) bytes = 1u << 20;
+    if (bytes > g_flush_bytes) {
+        if (g_flush_buf) HIP_TRY(hipFree(g_flush_buf));
+        g_flush_buf = nullptr;
+        g_flush_bytes = 0;
+        HIP_TRY(hipMalloc(&g_flush_buf, bytes));
+        HIP_TRY(hipMemset(g_flush_buf, 0, bytes));
+        g_flush_bytes = bytes;
+    }
+    unsigned *sink = nullptr;
+    const int grid = g_num_cus * 8;
+    HIP_TRY(hipMalloc((void **)&sink, (size_t)grid * sizeof(unsigned)));
+    std::vector<float> ms((size_t)iters, 0.f);
+    const int rc = time_loop(warmup, iters, ms.data(),
+                             [&]() {
+                                 hipLaunchKernelGGL(stream_probe_kernel, dim3(grid), dim3(kBlock), 0, g_stream,
+                                                    (const uint4 *)g_flush_buf, bytes / 16, sink);
+                                 hipError_t e = hipGetLastError();
+                                 return e == hipSuccess ? 0 : fail("stream_probe launch: %s", hipGetErrorString(e));
+                             },
+                             []() { return 0; });
+    (void)hipFree(sink);
+    if (rc) return rc;
+    double sum = 0;
+    float mn = ms[0];
+    for (float v : ms) {
+        sum += v;
+        mn = std::min(mn, v);
+    }
+    if (ms_mean) *ms_mean = (float)(sum / iters);
+    if (ms_min) *ms_min = mn;
     return 0;
 }
 

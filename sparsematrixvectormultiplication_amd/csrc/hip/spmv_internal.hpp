@@ -190,6 +190,9 @@ struct spmv_csr_dev {
     int auto_variant = SPMV_CSR_STREAM;
     int max_row = 0;
     size_t device_bytes = 0;
+    // arrays moved to a chosen address (spmv_hip_csr_relocate): the field points INTO `raw`, which is what gets freed
+    struct relocated { void **field; void *raw; size_t size; };
+    std::vector<relocated> relocs;
 };
 
 struct spmv_hll_dev {

@@ -60,6 +60,66 @@ def flush_cache(nbytes: int = 1 << 30) -> None:
     _check(nat.lib().spmv_hip_flush_cache(int(nbytes)), "spmv_hip_flush_cache")
 
 
+def stream_probe(nbytes: int = 1 << 30, warmup: int = 3, iters: int = 10):
+    """(mean, min) ms of a read-only 16-byte-per-lane stream over `nbytes` of HBM (spmv_hip_stream_probe)."""
+    mean, mn = C.c_float(0), C.c_float(0)
+    _check(nat.lib().spmv_hip_stream_probe(int(nbytes), int(warmup), int(iters), C.byref(mean), C.byref(mn)),
+           "spmv_hip_stream_probe")
+    return float(mean.value), float(mn.value)
+
+
+def _read(path, limit=400):
+    try:
+        with open(path) as fh:
+            return fh.read(limit).strip()
+    except OSError:
+        return None
+
+
+def box_state(probe_bytes: int = 1 << 30) -> dict:
+    """What distinguishes one GPU box of the pool from another, for bench records: the HIP attributes
+    (spmv_hip_device_state), the card's sysfs state (partition modes, DPM clock tables with the active level,
+    power cap, VBIOS) found through its PCI bus id, and the time of a read-only stream over 1 GiB."""
+    import glob
+    import os
+    buf = C.create_string_buffer(512)
+    _check(nat.lib().spmv_hip_device_state(buf, 512), "spmv_hip_device_state")
+    out = dict(item.split("=", 1) for item in buf.value.decode().split(";") if "=" in item)
+    for k in ("cus", "xcds", "sclk_khz", "mclk_khz", "mem_bus_bits", "l2_bytes", "hbm_bytes", "hbm_free_bytes"):
+        if k in out:
+            out[k] = int(out[k])
+    pci = out.get("pci", "").lower()
+    card = None
+    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if pci and os.path.basename(os.path.realpath(dev)).lower() == pci:
+            card = dev
+            break
+    sysfs = {}
+    if card:
+        for name in ("current_compute_partition", "current_memory_partition", "pp_dpm_sclk", "pp_dpm_mclk",
+                     "pp_dpm_fclk", "pp_dpm_socclk", "power_dpm_force_performance_level", "vbios_version",
+                     "mem_info_vram_used", "unique_id"):
+            v = _read(os.path.join(card, name))
+            if v is not None:
+                # DPM tables: keep the active level ("*") only
+                if name.startswith("pp_dpm_"):
+                    act = [ln for ln in v.splitlines() if ln.rstrip().endswith("*")]
+                    v = {"active": act[0].rstrip(" *") if act else None, "levels": len(v.splitlines())}
+                sysfs[name] = v
+        for hw in sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*"))):
+            for name in ("power1_cap", "power1_average", "power1_input", "temp1_input", "freq1_input", "freq2_input"):
+                v = _read(os.path.join(hw, name))
+                if v is not None:
+                    sysfs[name] = v
+    out["sysfs_card"] = card
+    out["sysfs"] = sysfs
+    if probe_bytes:
+        mean, mn = stream_probe(probe_bytes, 3, 10)
+        out["stream_probe"] = {"bytes": int(probe_bytes), "ms_mean": round(mean, 5), "ms_min": round(mn, 5),
+                               "gbps_mean": round(probe_bytes / (mean * 1e-3) / 1e9, 1)}
+    return out
+
+
 def set_tuning(key: str, value: int) -> None:
     """A/B knobs of the stream kernel: stream_cap (at upload), stream_nt, stream_xcd."""
     _check(nat.lib().spmv_hip_set_tuning(key.encode(), int(value)), "spmv_hip_set_tuning")
@@ -144,6 +204,17 @@ class CsrDevice(_Handle):
         out = nat.DevInfo()
         _check(nat.lib().spmv_hip_csr_info(self.h, C.byref(out)), "spmv_hip_csr_info")
         return out.as_dict()
+
+    def addresses(self) -> dict:
+        out = (C.c_ulonglong * 8)()
+        _check(nat.lib().spmv_hip_csr_addresses(self.h, out), "spmv_hip_csr_addresses")
+        return dict(zip(("row_ptr", "col", "val", "x", "y", "lcol", "lines", "ldesc4"), (int(v) for v in out)))
+
+    ARRAYS = ("row_ptr", "col", "val", "x", "y", "lcol", "lines", "ldesc4")
+
+    def relocate(self, which: str, align: int, offset: int):
+        _check(nat.lib().spmv_hip_csr_relocate(self.h, self.ARRAYS.index(which), int(align), int(offset)),
+               "spmv_hip_csr_relocate")
 
     def set_x(self, x):
         x = np.ascontiguousarray(x, dtype=self.dtype)

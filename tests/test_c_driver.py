@@ -123,6 +123,45 @@ def test_bench_row_partitioned_two_ranks_sharing_the_gpu(gpu):
 
 
 @pytest.mark.gpu
+def test_bench_powerlaw_two_ranks_checked_against_the_oracle(gpu):
+    """BASELINE configs[4]'s workload (power-law rows, fp32) through the N > 1 host path at a size the oracle
+    finishes in seconds: nnz-balanced split of very unequal rows, fp32 exchange, every rank checks the gathered
+    y against K1's loop with a double accumulator (fp32 has no reference counterpart: norm-wise 1e-5)."""
+    import json
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "powerlaw", "--powerlaw-n", "262144", "--exchange", "gloo-host", "--check",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["dtype"] == "f32" and out["value"] > 0
+    assert sum(out["config"]["rows_per_rank"]) == 262144
+    assert out["config"]["nnz_imbalance_max_over_mean"] < 1.2
+    assert proc.stderr.count("check: max|y - y_ref|") == 2
+
+
+@pytest.mark.gpu
+def test_bench_job_ends_nonzero_when_one_rank_fails(gpu):
+    """An unattended multi-rank run must not hang on a dead rank: rank 1 raises before the timed region while
+    rank 0 goes on into its first collective; the job has to end with a non-zero code well inside a minute."""
+    import sys
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--grid", "24,24,24", "--exchange", "gloo-host", "--no-cpu-baseline", "--fail-rank", "1",
+           "--dist-timeout", "30"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t = time.time()
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    took = time.time() - t
+    assert proc.returncode != 0, proc.stdout[-1000:]
+    assert "--fail-rank" in proc.stderr
+    assert not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")], "a failed job printed a result line"
+    assert took < 60, f"the job took {took:.0f} s to notice the dead rank"
+
+
+@pytest.mark.gpu
 def test_native_communicator_under_torch_first_load_order(gpu):
     """bench.py imports torch before libspmv_amd.so, so the C-ABI's RCCL calls bind to the
     librccl that torch ships, not /opt/rocm's.  Same single-rank exchange in that load order."""
