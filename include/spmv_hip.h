@@ -215,10 +215,17 @@ int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out);
 /* device addresses of the handle's arrays (placement studies): out[8] = row_ptr, col, val, x, y, lcol, lines, ldesc4
  * (0 where the handle has none) */
 int spmv_hip_csr_addresses(const spmv_csr_dev *m, unsigned long long *out);
+/* Measurement only: one launch of the x-window kernel (fp64, 2048-entry stage) with per-workgroup time stamps behind
+ * `warm` ordinary launches: stamps[3 * b + {0, 1, 2}] = start, end (ticks of the constant 100 MHz clock), dispatch id << 8
+ * | XCD of block b; stamps has 3 * local_blocks entries. */
+int spmv_hip_csr_stamp_blocks(spmv_csr_dev *m, int warm, unsigned long long *stamps);
 /* Move one array of the handle (same numbering) to an address of the form (multiple of `align`) + offset; align a
  * power of two >= 256, offset a multiple of 256 below it.  Round 3 found the x-window kernel's time on the headline
  * matrix to depend on where its arrays lie (profiles/r3_placement_*.txt); this is the tool that study used. */
 int spmv_hip_csr_relocate(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset);
+/* the same with memory from HIP's virtual-memory API (hipMemCreate / hipMemAddressReserve / hipMemMap): the virtual
+ * address is aligned to `align` exactly as asked, whatever hipMalloc would have chosen */
+int spmv_hip_csr_relocate_vmm(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset);
 
 /* library-owned vectors: host -> x, run, y -> host (y has M_total entries;
  * this handle writes rows [row0, row0 + M_local) of it) */
@@ -351,6 +358,16 @@ int spmv_hip_csr_power_iterate(spmv_csr_dev *m, int variant, int iters, const in
  *   spmv_hip_csr_power_iterate_halo   uses it when a communicator exists: the halo exchange runs on a second
  *                                 stream beside the interior blocks, the boundary blocks wait for its event
  *                                 ("halo_overlap" tuning knob 1 | 0) */
+/* N4, the second skeleton: `iters` steps of plain conjugate gradients for a symmetric positive definite A, from
+ * x0 = 0: p is the handle's x (gathered / halo-exchanged every step exactly as in the power iteration: bounds = the
+ * row partition when a communicator exists; use_halo != 0 after spmv_hip_comm_halo_setup), q = A p its y, every rank
+ * keeps its rows of x and r.  Dot products are fixed-order device reductions; across ranks the partial sums are
+ * all-gathered and added in rank order by every rank (same bits everywhere).  No host synchronisation in the loop.
+ * b_host: the right-hand side, M_total values of the handle's dtype (a rank reads its own rows).  Out: x_host
+ * (optional) the iterate after `iters` steps, M_total values; rr_hist (optional) [iters + 1] the squared residual
+ * norm r.r before the first step and after every step; *ms_total device time of the loop. */
+int spmv_hip_csr_cg(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_halo, const void *b_host,
+                    void *x_host, double *rr_hist, float *ms_total);
 int spmv_hip_csr_split_interior(spmv_csr_dev *m, long long *counts);
 int spmv_hip_csr_run_part(spmv_csr_dev *m, int part, const void *d_x, void *d_y, void *stream);
 int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count);

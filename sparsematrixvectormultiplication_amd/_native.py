@@ -148,7 +148,9 @@ _PROTOTYPES = {
     "spmv_hip_device_state": (C.c_int, [C.c_char_p, C.c_size_t]),
     "spmv_hip_stream_probe": (C.c_int, [C.c_size_t, C.c_int, C.c_int, c_float_p, c_float_p]),
     "spmv_hip_csr_addresses": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "spmv_hip_csr_stamp_blocks": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]),
     "spmv_hip_csr_relocate": (C.c_int, [C.c_void_p, C.c_int, C.c_ulonglong, C.c_ulonglong]),
+    "spmv_hip_csr_relocate_vmm": (C.c_int, [C.c_void_p, C.c_int, C.c_ulonglong, C.c_ulonglong]),
     "spmv_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "spmv_hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "spmv_hip_free": (C.c_int, [C.c_void_p]),
@@ -200,6 +202,8 @@ _PROTOTYPES = {
     "spmv_hip_csr_tile_auto_plan": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, C.POINTER(C.c_longlong)]),
     "spmv_hip_csr_power_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, c_double_p,
                                              c_float_p]),
+    "spmv_hip_csr_cg": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, C.c_void_p, C.c_void_p, c_double_p,
+                                  c_float_p]),
     "spmv_hip_csr_needed_ranges": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
     "spmv_hip_csr_split_interior": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "spmv_hip_csr_run_part": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

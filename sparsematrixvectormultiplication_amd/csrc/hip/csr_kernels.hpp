@@ -454,7 +454,9 @@ __device__ __forceinline__ void local_stage_full(T *stage, const int *__restrict
     for (int u = 0; u < kUnits; ++u) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = v[u];
 }
 
-template <typename T, bool NT, int CAP>
+// STAMP (measurement only, spmv_hip_csr_stamp_blocks): every workgroup leaves {start, end} of the constant 100 MHz
+// clock and the XCD it ran on in stamps[3 * block ..]; the product instantiation (STAMP = false) has no trace of it.
+template <typename T, bool NT, int CAP, bool STAMP = false>
 __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int xcd_chunk,
                                                            const int *__restrict__ ids,
                                                            const int4 *__restrict__ desc,
@@ -463,8 +465,11 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
                                                            const int *__restrict__ row_ptr,
                                                            const unsigned short *__restrict__ lcol,
                                                            const T *__restrict__ val,
-                                                           const T *__restrict__ x, T *__restrict__ y) {
+                                                           const T *__restrict__ x, T *__restrict__ y,
+                                                           unsigned long long *__restrict__ stamps = nullptr) {
         using V2 = typename vec2<T>::type;
+    unsigned long long t_start = 0;
+    if constexpr (STAMP) t_start = __builtin_amdgcn_s_memrealtime();
     constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
     // one LDS stage, used twice: first the x lines of the block, then (after every lane has
     // gathered its x values into registers) the CAP products.  max(CAP values, staged lines).
@@ -531,6 +536,15 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
     }
     __syncthreads();
     sum_rows_from_lds<T, kBlock>(stage, row_ptr, y, r0, nrows, base, lanes, seg_lo - base, seg_hi - base);
+    if constexpr (STAMP) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            stamps[3 * (size_t)b] = t_start;
+            stamps[3 * (size_t)b + 1] = __builtin_amdgcn_s_memrealtime();
+            // HW_REG_XCC_ID (20), bits 3:0: the XCD this workgroup ran on; next to it the dispatch id
+            stamps[3 * (size_t)b + 2] = ((unsigned long long)blockIdx.x << 8) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xf);
+        }
+    }
 }
 
 // ----------------------------------------------------------------- long rows

@@ -178,11 +178,43 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
         int lo1, m1;
         row_range(0, lo1, m1);
         if (lo1 + m1 > stage_slots) {
-            // a single row longer than the stage: whole workgroup, registers only
-            const long long at = base + lo1;
-            T acc = 0;
-            for (int j = t; j < m1; j += kBlock) acc += AS[at + j] * gather(x, JA[at + j]);
-            acc = group_sum<64>(acc);
+            // a single row longer than the stage: whole workgroup, registers only.  Trips of 8 units of pair loads
+            // (16 loads per lane in flight, as csr_long_pieces does): a circuit-like slab -- a few rows that touch
+            // everything, hence hacks of 32 rows x tens of thousands of slots -- spent its time in this loop when it
+            // took one dependent load at a time (dc1-size stand-in: 60 us against 12 us for the same matrix as CSR)
+            using V2 = typename vec2<T>::type;
+            constexpr int kUnits = 8;
+            const long long n0 = base + lo1, n1 = n0 + m1;
+            T a0 = 0, a1 = 0;
+            long long e0 = (n0 & ~1LL) + 2 * t;
+            for (; e0 - 2 * t + kUnits * kStreamUnit <= n1; e0 += kUnits * kStreamUnit) {
+                v2i c[kUnits];
+                V2 v[kUnits];
+#pragma unroll
+                for (int u = 0; u < kUnits; ++u) {
+                    c[u] = stream_load<NT>(reinterpret_cast<const v2i *>(JA + e0 + u * kStreamUnit));
+                    v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(AS + e0 + u * kStreamUnit));
+                }
+                T xv[2 * kUnits];
+#pragma unroll
+                for (int u = 0; u < kUnits; ++u) {
+                    xv[2 * u] = gather(x, c[u].x);
+                    xv[2 * u + 1] = gather(x, c[u].y);
+                }
+                if (e0 < n0) v[0].x = T(0);  // only lane 0 of the first trip of a row that starts on an odd slot
+#pragma unroll
+                for (int u = 0; u < kUnits; ++u) {
+                    a0 += v[u].x * xv[2 * u];
+                    a1 += v[u].y * xv[2 * u + 1];
+                }
+            }
+            for (; e0 < n1; e0 += kStreamUnit) {  // remainder: bounded per slot
+                const v2i c = stream_load<NT>(reinterpret_cast<const v2i *>(JA + e0));
+                const V2 v = stream_load<NT>(reinterpret_cast<const V2 *>(AS + e0));
+                if (e0 >= n0) a0 += v.x * gather(x, c.x);
+                if (e0 + 1 < n1) a1 += v.y * gather(x, c.y);
+            }
+            T acc = group_sum<64>(a0 + a1);
             if ((t & 63) == 0) wave_part[t >> 6] = acc;
             __syncthreads();
             if (t == 0) {

@@ -840,3 +840,200 @@ extern "C" int spmv_hip_csr_power_iterate_halo(spmv_csr_dev *m, int variant, int
     (void)hipFree(d_norm);
     return rc;
 }
+
+// ------------------------------------------------------------- conjugate gradients
+// SURVEY.md 8(f) N4, the second iterated skeleton (the reference multiplies by a fixed x; a Krylov method is what
+// an SpMV engine is for).  Plain CG for a symmetric positive definite A, x0 = 0:
+//     r = b, p = b, rs = r.r;   repeat:  q = A p;  alpha = rs / p.q;  x += alpha p;  r -= alpha q;
+//                                        rs' = r.r;  beta = rs' / rs;  p = r + beta p;  rs = rs'
+// p is the handle's x (the SpMV input, full length on every rank), q its y (this rank's rows).  Every rank keeps
+// its own rows of x, r; the SpMV's exchange is the same as in the power iteration -- all-gatherv of p, or the
+// halo exchange when spmv_hip_comm_halo_setup has run and use_halo is set.  Dot products are fixed-order device
+// reductions (grid-stride partial sums per workgroup, folded by one workgroup); across ranks the partial sums are
+// ALL-GATHERED and added in rank order by every rank, so all ranks hold the same bits whatever reduction tree the
+// collective library would pick for an all-reduce.  Scalars stay on the device: no host synchronisation in the loop.
+namespace {
+
+constexpr int kCgRs = 0, kCgPq = 1, kCgRsNew = 2, kCgAlpha = 3, kCgBeta = 4, kCgLocal = 5, kCgScalars = 8;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dot_partial(const T *__restrict__ a, const T *__restrict__ b, long long n,
+                                                      double *__restrict__ part) {
+    __shared__ double wave_sum[kBlock / 64];
+    double acc = 0;
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock)
+        acc += (double)a[k] * (double)b[k];
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = wave_sum[0];
+        for (int w = 1; w < kBlock / 64; ++w) s += wave_sum[w];
+        part[blockIdx.x] = s;
+    }
+}
+
+// x += alpha p, r -= alpha q on this rank's rows, and the workgroup's partial of the new r.r
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_update_x_r(long long n, const double *__restrict__ s, const T *__restrict__ p,
+                                                        const T *__restrict__ q, T *__restrict__ x, T *__restrict__ r,
+                                                        double *__restrict__ part) {
+    __shared__ double wave_sum[kBlock / 64];
+    const double alpha = s[kCgAlpha];
+    double acc = 0;
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) {
+        x[k] = (T)((double)x[k] + alpha * (double)p[k]);
+        const T rk = (T)((double)r[k] - alpha * (double)q[k]);
+        r[k] = rk;
+        acc += (double)rk * (double)rk;
+    }
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wave_sum[0];
+        for (int w = 1; w < kBlock / 64; ++w) t += wave_sum[w];
+        part[blockIdx.x] = t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_update_p(long long n, const double *__restrict__ s, const T *__restrict__ r,
+                                                      T *__restrict__ p) {
+    const double beta = s[kCgBeta];
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock)
+        p[k] = (T)((double)r[k] + beta * (double)p[k]);
+}
+
+// the ranks' partial sums in rank order -> s[slot]
+__global__ void cg_rank_sum(const double *__restrict__ gathered, int ranks, double *__restrict__ s, int slot) {
+    double t = 0;
+    for (int k = 0; k < ranks; ++k) t += gathered[k];
+    s[slot] = t;
+}
+__global__ void cg_set_alpha(double *__restrict__ s) { s[kCgAlpha] = s[kCgPq] != 0.0 ? s[kCgRs] / s[kCgPq] : 0.0; }
+__global__ void cg_set_beta(double *__restrict__ s, double *__restrict__ hist, int k) {
+    s[kCgBeta] = s[kCgRs] != 0.0 ? s[kCgRsNew] / s[kCgRs] : 0.0;
+    s[kCgRs] = s[kCgRsNew];
+    if (hist) hist[k] = s[kCgRsNew];
+}
+__global__ void cg_record(const double *__restrict__ s, double *__restrict__ hist) { hist[0] = s[kCgRs]; }
+
+// part[0 .. grid) of this rank -> the global sum in s[slot] on every rank
+int cg_reduce(double *d_part, int grid, double *d_s, double *d_gath, int slot) {
+    if (!g_comm) {
+        hipLaunchKernelGGL(fold_partials, dim3(1), dim3(kBlock), 0, g_stream, d_part, grid, d_s + slot);
+        return 0;
+    }
+    hipLaunchKernelGGL(fold_partials, dim3(1), dim3(kBlock), 0, g_stream, d_part, grid, d_s + kCgLocal);
+    const ncclResult_t n = ncclAllGather(d_s + kCgLocal, d_gath, 1, ncclDouble, g_comm, g_stream);
+    if (n != ncclSuccess) return fail("csr_cg: ncclAllGather failed: %s", ncclGetErrorString(n));
+    hipLaunchKernelGGL(cg_rank_sum, dim3(1), dim3(1), 0, g_stream, d_gath, g_comm_size, d_s, slot);
+    return 0;
+}
+
+int cg_exchange_p(spmv_csr_dev *m, const int *bounds, int use_halo) {
+    if (!g_comm) return 0;
+    if (use_halo) return spmv_hip_comm_halo_exchange(m->x, m->value_bytes, g_stream);
+    return spmv_hip_comm_allgatherv(m->x, bounds, m->value_bytes, g_stream);
+}
+
+template <typename T>
+int cg_run(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_halo, T *d_xs, T *d_r, double *d_s,
+           double *d_part, double *d_gath, double *d_hist) {
+    const long long n = m->M_local;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(kNormBlocks, (n + kBlock - 1) / kBlock));
+    T *p_own = (T *)m->x + m->row0, *q_own = (T *)m->y + m->row0, *x_own = d_xs + m->row0;
+    // rs = r.r with r = b (already in d_r and in p's own range); every rank gets the whole p
+    hipLaunchKernelGGL((dot_partial<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)d_r, (const T *)d_r, n, d_part);
+    if (cg_reduce(d_part, grid, d_s, d_gath, kCgRs)) return -1;
+    hipLaunchKernelGGL(cg_record, dim3(1), dim3(1), 0, g_stream, d_s, d_hist);
+    if (cg_exchange_p(m, bounds, use_halo)) return -1;
+    for (int k = 0; k < iters; ++k) {
+        if (csr_launch_any(m, variant, m->x, m->y, g_stream)) return -1;  // q = A p on this rank's rows
+        hipLaunchKernelGGL((dot_partial<T>), dim3(grid), dim3(kBlock), 0, g_stream, (const T *)p_own, (const T *)q_own, n, d_part);
+        if (cg_reduce(d_part, grid, d_s, d_gath, kCgPq)) return -1;
+        hipLaunchKernelGGL(cg_set_alpha, dim3(1), dim3(1), 0, g_stream, d_s);
+        hipLaunchKernelGGL((cg_update_x_r<T>), dim3(grid), dim3(kBlock), 0, g_stream, n, d_s, (const T *)p_own,
+                           (const T *)q_own, x_own, d_r, d_part);
+        if (cg_reduce(d_part, grid, d_s, d_gath, kCgRsNew)) return -1;
+        hipLaunchKernelGGL(cg_set_beta, dim3(1), dim3(1), 0, g_stream, d_s, d_hist, k + 1);
+        hipLaunchKernelGGL((cg_update_p<T>), dim3(grid), dim3(kBlock), 0, g_stream, n, d_s, (const T *)d_r, p_own);
+        if (cg_exchange_p(m, bounds, use_halo)) return -1;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int cg_body(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_halo, const void *b_host, void *x_host,
+            double *rr_hist, float *ms_total) {
+    const size_t n_all = (size_t)m->M_total, n_own = (size_t)m->M_local;
+    T *d_xs = nullptr, *d_r = nullptr;
+    double *d_s = nullptr, *d_part = nullptr, *d_gath = nullptr, *d_hist = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    do {
+        hipError_t e = hipMalloc((void **)&d_xs, std::max<size_t>(n_all, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_r, std::max<size_t>(n_own, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_s, kCgScalars * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_part, kNormBlocks * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_gath, kMaxRanks * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_hist, ((size_t)iters + 1) * sizeof(double));
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipMemsetAsync(d_xs, 0, std::max<size_t>(n_all, 1) * sizeof(T), g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_s, 0, kCgScalars * sizeof(double), g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, ((size_t)iters + 1) * sizeof(double), g_stream);
+        // r = b on this rank's rows; p = b: the own range of the handle's x (the rest arrives by the exchange)
+        if (e == hipSuccess && n_own)
+            e = hipMemcpyAsync(d_r, (const T *)b_host + m->row0, n_own * sizeof(T), hipMemcpyHostToDevice, g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(m->x, 0, (size_t)m->N * sizeof(T), g_stream);
+        if (e == hipSuccess && n_own)
+            e = hipMemcpyAsync((T *)m->x + m->row0, d_r, n_own * sizeof(T), hipMemcpyDeviceToDevice, g_stream);
+        if (e == hipSuccess) e = hipEventRecord(e0, g_stream);
+        if (e != hipSuccess) { rc = fail("csr_cg: setup failed: %s", hipGetErrorString(e)); break; }
+        rc = cg_run<T>(m, variant, iters, bounds, use_halo, d_xs, d_r, d_s, d_part, d_gath, d_hist);
+        if (rc) {
+            (void)hipStreamSynchronize(g_stream);
+            break;
+        }
+        e = hipEventRecord(e1, g_stream);
+        // the solution: every rank holds its rows; with a communicator all rows everywhere
+        if (e == hipSuccess && g_comm && x_host) {
+            if (spmv_hip_comm_allgatherv(d_xs, bounds, m->value_bytes, g_stream)) { rc = -1; break; }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && x_host) e = hipMemcpy(x_host, d_xs, n_all * sizeof(T), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rr_hist) e = hipMemcpy(rr_hist, d_hist, ((size_t)iters + 1) * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail("csr_cg: run failed: %s", hipGetErrorString(e)); break; }
+        if (ms_total) *ms_total = ms;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_xs);
+    (void)hipFree(d_r);
+    (void)hipFree(d_s);
+    (void)hipFree(d_part);
+    (void)hipFree(d_gath);
+    (void)hipFree(d_hist);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int spmv_hip_csr_cg(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_halo,
+                               const void *b_host, void *x_host, double *rr_hist, float *ms_total) {
+    if (need_device()) return -1;
+    if (!m || iters < 0 || !b_host) return fail("csr_cg: bad arguments");
+    if (m->M_total != m->N) return fail("csr_cg: needs a square matrix (%d x %d)", m->M_total, m->N);
+    if (g_comm && !bounds) return fail("csr_cg: a communicator exists, the row bounds are required");
+    if (g_comm && use_halo && !g_halo_ready) return fail("csr_cg: call spmv_hip_comm_halo_setup first");
+    if (g_comm_size > kMaxRanks) return fail("csr_cg: more than %d ranks", kMaxRanks);
+    return guarded("csr_cg", [&] {
+        return m->value_bytes == 8 ? cg_body<double>(m, variant, iters, bounds, use_halo, b_host, x_host, rr_hist, ms_total)
+                                   : cg_body<float>(m, variant, iters, bounds, use_halo, b_host, x_host, rr_hist, ms_total);
+    });
+}

@@ -36,8 +36,12 @@ void csr_build_blocks(int M, const int *rp, int cap, int rows_cap, std::vector<i
             ++r;
             continue;
         }
-        int r1 = r;
-        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && !is_long(r1)) ++r1;
+        int r1 = r, maxlen = 0;
+        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && !is_long(r1) &&
+               !skew_cut(r1 - r, maxlen, rp[r1 + 1] - rp[r1])) {
+            maxlen = std::max(maxlen, rp[r1 + 1] - rp[r1]);
+            ++r1;
+        }
         desc.push_back(int4{r, n0, r1 - r, rp[r1]});
         r = r1;
     }
@@ -280,12 +284,14 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
 // 64 KiB.  Done once per value type, at upload (not at launch: a launch may sit inside a graph capture).
 template <typename T>
 int tile_allow_lds() {
-    static bool done = false;
+    // the attribute belongs to (function, device): spmv_hip_init may have switched devices since the last upload
+    static int done_for_device = -1;
+    const bool done = done_for_device == g_device;
     if (done) return 0;
     const void *fns[4] = {(const void *)csr_tile<T, false, 2048, kTileTrips, false>, (const void *)csr_tile<T, true, 2048, kTileTrips, false>,
                           (const void *)csr_tile<T, false, 2048, kTileTrips, true>, (const void *)csr_tile<T, true, 2048, kTileTrips, true>};
     for (const void *fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
+    done_for_device = g_device;
     return 0;
 }
 
@@ -293,7 +299,9 @@ int tile_allow_lds() {
 template <typename T>
 int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
     int rc = 0;
-    if ((tb.have_tiles || tb.have_long_tiles) && tile_allow_lds<T>()) return -1;
+    // the kernels need more than 64 KiB of dynamic LDS: where the device will not allow that the handle simply gets
+    // no tiles and keeps its gather kernels (return 1; the message stays in spmv_hip_last_error)
+    if ((tb.have_tiles || tb.have_long_tiles) && tile_allow_lds<T>()) return 1;
     if (tb.have_tiles) {
         const TilePlan<T> &tiles = tb.tiles;
         // (the kernel walks STREAMS: descriptors in stream order, the passes / blocks of every stream, the blocks' rows)
@@ -408,8 +416,9 @@ bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, 
         }
         const int blk = (int)plan.desc.size();
         cur.clear();
-        int r1 = r;
-        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && rp[r1 + 1] - rp[r1] <= cap - 3) {
+        int r1 = r, maxlen = 0;
+        while (r1 < M && r1 - r < rows_cap && rp[r1 + 1] - base <= cap && rp[r1 + 1] - rp[r1] <= cap - 3 &&
+               !skew_cut(r1 - r, maxlen, rp[r1 + 1] - rp[r1])) {
             const size_t before = cur.size();
             for (int e = rp[r1]; e < rp[r1 + 1]; ++e) {
                 const int l = col[e] >> line_shift;
@@ -423,11 +432,16 @@ bool csr_build_local(int M, int N, const int *rp, const int *col, long long nz, 
                 cur.resize(before);
                 break;
             }
+            maxlen = std::max(maxlen, rp[r1 + 1] - rp[r1]);
             ++r1;
         }
         if (r1 == r) {
             // one row alone touches more lines than a block may list: it goes to the split-row
             // (gather) kernels like a long row; a matrix made of such rows keeps the gather kernel
+            // ... and a SMALL matrix with such a row keeps it too: the split-row kernels are two more launches
+            // (~5 us), more than the whole product of a matrix below ~1 M entries (adder_dcop_32-size stand-in:
+            // 11.5 us with the plan + split rows against 6.3 us for one launch, profiles/r2_reference_list_stand_ins.md)
+            if (nz < kSplitMinEntries) return false;
             plan.split[r] = 1;
             split_entries += rp[r + 1] - n0;
             if (split_entries * 20 > nz) return false;
@@ -715,7 +729,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     if (!rc && m->num_long) rc |= upload_array(&m->long_rows, long_rows.data(), long_rows.size(), 0);
     if (!rc && num_partial) rc |= upload_array(&m->pieces, pieces.data(), pieces.size(), 0);
     const size_t bytes_before_tiles = m->device_bytes;
-    if (!rc) rc |= tile_upload_all<T>(m, tb);
+    if (!rc && tile_upload_all<T>(m, tb) < 0) rc = -1;  // (1 = the device refused the LDS size: no tiles, not an error)
     const size_t tile_bytes = m->device_bytes - bytes_before_tiles;  // (device_bytes is recomputed below)
     const int partial_slots = std::max(num_partial, (int)tb.tile_pieces.size());
     if (!rc && partial_slots) {
@@ -792,11 +806,18 @@ static int spmv_hip_csr_plan_check_body(int M, int N, const int *row_ptr, const 
         }
         return 0;
     };
+    // no lane of the row-sum phase adds up more than kSkewPerLane entries unless its row is alone in the block
+    auto lane_load_ok = [&](const int4 &d) {
+        int longest = 0;
+        for (int r = d.x; r < d.x + d.z; ++r) longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
+        return d.z == 1 || longest / host_lanes_for_rows(d.z) <= kSkewPerLane;
+    };
     for (const int4 &d : desc) {
         if (claim(d.x, d.z, "gather block")) return -1;
         if (d.z <= 0 || d.z > kStreamRowsCap || d.y != row_ptr[d.x] || d.w != row_ptr[d.x + d.z] ||
             d.w - (d.y & kBaseMask) > cap)
             return fail("plan_check: gather block at row %d is malformed", d.x);
+        if (!lane_load_ok(d)) return fail("plan_check: gather block at row %d leaves a long row to too few lanes", d.x);
     }
     int split_rows = 0;
     for (const int4 &l : long_rows) {
@@ -825,6 +846,7 @@ static int spmv_hip_csr_plan_check_body(int M, int N, const int *row_ptr, const 
             if (d.z <= 0 || d.z > kStreamRowsCap || d.y != row_ptr[d.x] || d.w != row_ptr[d.x + d.z] ||
                 d.w - (d.y & kBaseMask) > cap)
                 return fail("plan_check: x-window block at row %d is malformed", d.x);
+            if (!lane_load_ok(d)) return fail("plan_check: x-window block at row %d leaves a long row to too few lanes", d.x);
             if (ld.y < 1 || ld.y > kLocalLinesMax || ld.x < 0 || (size_t)ld.x + ld.y > plan.lines.size())
                 return fail("plan_check: line list of block %zu is malformed", b);
             for (int k = 1; k < ld.y; ++k)
@@ -1115,13 +1137,26 @@ int csr_tiles_from_rows_f64(int M_local, int M_total, int row0, int N, const int
         m->nz = entries;
         m->tiles_only = true;
         m->auto_variant = SPMV_CSR_STREAM;
-        if (tile_upload_all<double>(m, tb)) {
+        const int trc = tile_upload_all<double>(m, tb);
+        if (trc) {  // 1: no tiles on this device (the slab keeps hll_lds), -1: a real failure
             spmv_hip_csr_free(m);
-            return -1;
+            return trc < 0 ? -1 : 0;
         }
         *out = m;
         return 0;
     });
+}
+
+static void release_relocated(spmv_csr_dev::relocated &r) {
+    if (!r.raw) return;
+    if (r.vmm) {
+        (void)hipMemUnmap(r.raw, r.mapped);
+        (void)hipMemAddressFree(r.raw, r.mapped);
+        (void)hipMemRelease(r.phys);
+    } else {
+        (void)hipFree(r.raw);
+    }
+    r.raw = nullptr;
 }
 
 extern "C" int spmv_hip_csr_upload(int M, int N, const int *row_ptr, const int *col_idx,
@@ -1143,7 +1178,7 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     if (!m) return;
     for (auto &r : m->relocs) {  // relocated arrays: the field points into r.raw
         *r.field = nullptr;
-        (void)hipFree(r.raw);
+        release_relocated(r);
     }
     (void)hipFree(m->row_ptr);
     (void)hipFree(m->col);
@@ -1190,7 +1225,11 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
 
 // Placement study / placement rule: move one array of the handle to an address of the form
 // (multiple of `align`) + offset.  which: 0 row_ptr, 1 col, 2 val, 3 x, 4 y, 5 lcol, 6 lines, 7 ldesc4.
-extern "C" int spmv_hip_csr_relocate(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset) {
+// vmm != 0: the new home is built with the virtual-memory API instead of hipMalloc -- physical memory from
+// hipMemCreate (one handle, size rounded to the recommended granularity), a virtual range reserved with the asked
+// alignment, mapped and made accessible: VA alignment is then ours to choose, the physical side is whatever the
+// driver's allocator gives a request of that size.
+static int relocate_impl(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset, int vmm) {
     if (need_device()) return -1;
     if (!m || which < 0 || which > 7) return fail("csr_relocate: bad arguments");
     if (align < 256 || (align & (align - 1)) || (offset & 255) || offset >= align)
@@ -1201,29 +1240,106 @@ extern "C" int spmv_hip_csr_relocate(spmv_csr_dev *m, int which, unsigned long l
     if (!*field) return 0;  // the handle has no such array
     HIP_TRY(hipStreamSynchronize(g_stream));
     size_t size = 0;
-    void *old_raw = *field;
     size_t at = m->relocs.size();
     for (size_t k = 0; k < m->relocs.size(); ++k)
         if (m->relocs[k].field == field) at = k;
-    if (at < m->relocs.size()) {
-        size = m->relocs[at].size;
-        old_raw = m->relocs[at].raw;
+    if (at < m->relocs.size()) size = m->relocs[at].size;
+    else HIP_TRY(hipMemPtrGetInfo(*field, &size));
+    spmv_csr_dev::relocated fresh;
+    fresh.field = field;
+    fresh.size = size;
+    char *p = nullptr;
+    if (!vmm) {
+        HIP_TRY(hipMalloc(&fresh.raw, size + align + offset));
+        p = (char *)(((uintptr_t)fresh.raw + align - 1) & ~(uintptr_t)(align - 1)) + offset;
     } else {
-        HIP_TRY(hipMemPtrGetInfo(*field, &size));
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = g_device;
+        size_t gran = 0;
+        HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        if (gran == 0) gran = 2u << 20;
+        fresh.vmm = true;
+        fresh.mapped = (size + offset + gran - 1) / gran * gran;
+        HIP_TRY(hipMemCreate(&fresh.phys, fresh.mapped, &prop, 0));
+        hipError_t e = hipMemAddressReserve(&fresh.raw, fresh.mapped, align, nullptr, 0);
+        if (e == hipSuccess) {
+            e = hipMemMap(fresh.raw, fresh.mapped, 0, fresh.phys, 0);
+            if (e == hipSuccess) {
+                hipMemAccessDesc acc = {};
+                acc.location = prop.location;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                e = hipMemSetAccess(fresh.raw, fresh.mapped, &acc, 1);
+                if (e != hipSuccess) (void)hipMemUnmap(fresh.raw, fresh.mapped);
+            }
+            if (e != hipSuccess) (void)hipMemAddressFree(fresh.raw, fresh.mapped);
+        }
+        if (e != hipSuccess) {
+            (void)hipMemRelease(fresh.phys);
+            return fail("csr_relocate: virtual-memory allocation failed: %s", hipGetErrorString(e));
+        }
+        if ((uintptr_t)fresh.raw & (align - 1)) {
+            release_relocated(fresh);
+            return fail("csr_relocate: the reserved range is not aligned to %llu", align);
+        }
+        p = (char *)fresh.raw + offset;
     }
-    void *raw = nullptr;
-    HIP_TRY(hipMalloc(&raw, size + align + offset));
-    char *p = (char *)(((uintptr_t)raw + align - 1) & ~(uintptr_t)(align - 1)) + offset;
     hipError_t e = hipMemcpy(p, *field, size, hipMemcpyDeviceToDevice);
     if (e != hipSuccess) {
-        (void)hipFree(raw);
+        release_relocated(fresh);
         return fail("csr_relocate: copy failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(old_raw);
+    if (at < m->relocs.size()) release_relocated(m->relocs[at]);
+    else (void)hipFree(*field);
     *field = p;
-    if (at < m->relocs.size()) m->relocs[at] = {field, raw, size};
-    else m->relocs.push_back({field, raw, size});
+    if (at < m->relocs.size()) m->relocs[at] = fresh;
+    else m->relocs.push_back(fresh);
     return 0;
+}
+
+extern "C" int spmv_hip_csr_relocate(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset) {
+    return guarded("csr_relocate", [&] { return relocate_impl(m, which, align, offset, 0); });
+}
+extern "C" int spmv_hip_csr_relocate_vmm(spmv_csr_dev *m, int which, unsigned long long align, unsigned long long offset) {
+    return guarded("csr_relocate_vmm", [&] { return relocate_impl(m, which, align, offset, 1); });
+}
+
+// Measurement only: one launch of the x-window kernel's STAMP instantiation (same code + three stores per workgroup)
+// behind `warm` ordinary launches; stamps[3 * b] = {start, end (ticks of the constant 100 MHz clock), dispatch id << 8 |
+// XCD} of block b.  Shows WHERE a slow launch loses its time: every block a little, or one XCD's share as a tail.
+extern "C" int spmv_hip_csr_stamp_blocks(spmv_csr_dev *m, int warm, unsigned long long *stamps_host) {
+    if (need_device()) return -1;
+    if (!m || !stamps_host) return fail("csr_stamp_blocks: NULL argument");
+    if (m->local_blocks <= 0 || m->value_bytes != 8 || m->local_cap != 2048)
+        return fail("csr_stamp_blocks: needs an fp64 handle with an x-window plan at the 2048-entry stage");
+    unsigned long long *d = nullptr;
+    const size_t bytes = (size_t)m->local_blocks * 3 * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc((void **)&d, bytes));
+    int rc = 0;
+    for (int i = 0; i < warm && !rc; ++i) rc = csr_launch_any(m, SPMV_CSR_STREAM, m->x, m->y, g_stream);
+    if (!rc) {
+        const int lcount = m->local_blocks;
+        const int lchunk = g_stream_xcd < 0 ? (lcount + 7) / 8 : (g_stream_xcd ? g_stream_xcd : 16);
+        const int lgrid = (lcount + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk);
+        const size_t lds = std::max((size_t)m->local_cap * sizeof(double), (size_t)m->local_stage_lines * kLineBytes);
+        const bool lnt = g_local_nt < 0 ? m->nz * 10LL > (128LL << 20) : g_local_nt != 0;
+        double *y = (double *)m->y + m->row0;
+        if (lnt)
+            hipLaunchKernelGGL((csr_stream_local<double, true, 2048, true>), dim3(lgrid), dim3(kBlock), lds, g_stream, lcount, lchunk,
+                               (const int *)nullptr, m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const double *)m->val,
+                               (const double *)m->x, y, d);
+        else
+            hipLaunchKernelGGL((csr_stream_local<double, false, 2048, true>), dim3(lgrid), dim3(kBlock), lds, g_stream, lcount, lchunk,
+                               (const int *)nullptr, m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const double *)m->val,
+                               (const double *)m->x, y, d);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        if (e == hipSuccess) e = hipMemcpy(stamps_host, d, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail("csr_stamp_blocks: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 extern "C" int spmv_hip_csr_addresses(const spmv_csr_dev *m, unsigned long long *out) {
@@ -1274,7 +1390,8 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
                             (m->lt.packed ? 2 : 0) * m->lt.staged +
                             16LL * (m->tile_passes + m->lt.passes) +
                             4LL * m->tile_blocks + 2 * vb * (long long)m->lt.items * m->lt.rows_per_block +
-                            (m->nz - m->tile_entries - m->lt.entries) * (vb + 4) + 16LL * m->tile_num_pieces +
+                            std::max<long long>(0, m->nz - m->tile_entries - m->tile_rem_entries - m->lt.entries) * (vb + 4) +
+                            m->tile_rem_entries * (vb + 4) + 16LL * m->tile_num_pieces +
                             vb * m->M_local + vb * m->N;
     return 0;
 }
@@ -1358,9 +1475,15 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                 // the x-window kernel reads whole aligned lines of x
                 const bool local = (g_stream_kind == -1 || g_stream_kind == 5) && m->local_blocks > 0 &&
                                    ((uintptr_t)x & (kLineBytes - 1)) == 0;
-                const bool tiled = !local && m->tile_blocks > 0 &&
+                // a PACKED plan copies its x slices as 16-byte pieces and has no gather code to fall back on: with an x
+                // that is not 16-byte aligned the clamp of the last piece no longer keeps the loads inside x, so such a
+                // launch goes to the gather kernels (a tiles-only handle has none: error)
+                const bool x_ok_for_tiles = !m->tile_packed || ((uintptr_t)x & 15) == 0;
+                const bool tiled = !local && m->tile_blocks > 0 && x_ok_for_tiles &&
                                    (g_stream_kind == -1 || g_stream_kind == 6 || m->tiles_only);
-                if (m->tiles_only && !tiled) return fail("csr_launch: a tiles-only handle has nothing else to run");
+                if (m->tiles_only && !tiled)
+                    return fail(x_ok_for_tiles ? "csr_launch: a tiles-only handle has nothing else to run"
+                                               : "csr_launch: a packed tile plan needs a 16-byte aligned x");
                 if (tiled) {
                     // staging copies 16-byte pieces of x: plans with gather passes fall back on gathering everything when
                     // x is not 16-byte aligned, packed plans (no gather code) load the pieces unaligned

@@ -38,7 +38,13 @@ long long hll_build_blocks(int M, int hacks, const long long *off, const int *mz
         const long long s0 = start_of(r);
         const long long base = s0 & ~1LL;
         int r1 = r + 1;  // the first row is always taken (even if it alone exceeds cap)
-        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap) ++r1;
+        int maxlen = mz[r / kHack];
+        // (skew_cut: a window on the border between a hack of short rows and one of long rows -- see spmv_internal.hpp)
+        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap &&
+               !skew_cut(r1 - r, maxlen, mz[r1 / kHack])) {
+            maxlen = std::max(maxlen, mz[r1 / kHack]);
+            ++r1;
+        }
         const long long span = start_of(r1 - 1) + mz[(r1 - 1) / kHack] - base;
         if (r1 - r > 1 || span <= cap) widest = std::max(widest, span);
         desc.push_back(int4{r, r1 - r, (int)(s0 & 0xffffffffLL), (int)(s0 >> 32)});
@@ -70,8 +76,9 @@ bool hll_build_local(int M, int N, const long long *off, const int *mz, const in
         const long long base = s0 & ~1LL;
         const int blk = (int)plan.desc.size();
         cur.clear();
-        int r1 = r;
-        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap) {
+        int r1 = r, maxlen = 0;
+        while (r1 < M && r1 - r < kStreamRowsCap && start_of(r1) + mz[r1 / kHack] - base <= cap &&
+               !skew_cut(r1 - r, maxlen, mz[r1 / kHack])) {
             const size_t before = cur.size();
             const long long a = start_of(r1);
             for (long long k = a; k < a + mz[r1 / kHack]; ++k) {
@@ -86,6 +93,7 @@ bool hll_build_local(int M, int N, const long long *off, const int *mz, const in
                 cur.resize(before);
                 break;
             }
+            maxlen = std::max(maxlen, mz[r1 / kHack]);
             ++r1;
         }
         if (r1 == r) return false;  // a row that alone exceeds the stage or the line limit
@@ -700,7 +708,9 @@ int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_fu
                                        m->lja, m->AS, x, y);
                 break;
             }
-            if (m->tiles && (g_stream_kind == -1 || g_stream_kind == 6))  // csr_tile over the slab's rows
+            // csr_tile over the slab's rows (a packed plan copies 16-byte pieces of x and has no gather code: a foreign x
+            // that is not 16-byte aligned goes to hll_lds below instead of being read past its end)
+            if (m->tiles && (g_stream_kind == -1 || g_stream_kind == 6) && (!m->tiles->tile_packed || ((uintptr_t)x & 15) == 0))
                 return csr_launch_any(m->tiles, SPMV_CSR_STREAM, x, y_full, s);
             const size_t lds = 32 + ((size_t)m->stage_slots + 2) * sizeof(double);
 #define SPMV_HLL_LDS_LAUNCH(MAXU)                                                                  \

@@ -49,6 +49,7 @@ extern int g_stream_tile;     // csr_tile plan at upload: -1 = auto (no x-window
 extern int g_tile_rows;       // rows per block: 0 = auto, else a power of two in 256..8192
 extern int g_tile_lmax;       // rows longer than this stay with the split-row kernels
 constexpr long long kTileMidEntries = 4LL << 20;  // (auto) ... or, for a band of dense rows, entries from which it gets one (packed plans only)
+constexpr long long kSplitMinEntries = 1LL << 20;  // entries from which rows may be handed to the split-row kernels (two more launches)
 constexpr long long kTileMinRows = 800000;  // (auto) rows from which a handle without an x-window plan gets a tile plan
 extern int g_tile_min_pass;   // windows of a packed plan with fewer entries than this (and sparser than 1 per 16 columns) go to the remainder; 0: none
 extern int g_tile_places;     // 0: the chip's (2 or 1 workgroups per CU) | the number of workgroup places the streams / the block count are made for
@@ -112,6 +113,23 @@ inline int pow2_floor(int v) {
     int p = 1;
     while (p * 2 <= v) p *= 2;
     return p;
+}
+
+// The row-sum phase of the stream / LDS kernels gives every row of a block the same number of lanes, sized by the
+// NUMBER of rows in the block (lanes_for_rows in csr_kernels.hpp; mirrored here for the host).  One row of hundreds of
+// entries in a block of hundreds of short rows is then summed by a single lane while the other 255 wait (circuit
+// matrices: adder_dcop_32-size stand-in 11.5 us where one launch costs 6.3).  Upload therefore closes a block before a
+// row -- or before more rows join a long one -- whenever some lane would have to add up more than kSkewPerLane entries:
+// the long row ends up in a block of few rows and gets 8..64 lanes.  Uniform matrices never get there (rows x length
+// <= stage, so length / lanes <= 32).
+constexpr int kSkewPerLane = 64;
+inline int host_lanes_for_rows(int nrows) {
+    if (nrows > kBlock / 2 || nrows <= 0) return 1;
+    return std::min(64, pow2_floor(kBlock / nrows));
+}
+inline bool skew_cut(int nrows, int maxlen, int len) {
+    if (nrows <= 0) return false;  // a block always takes its first row
+    return std::max(maxlen, len) / host_lanes_for_rows(nrows + 1) > kSkewPerLane;
 }
 
 // ---------------------------------------------------------------- handles
@@ -191,7 +209,8 @@ struct spmv_csr_dev {
     int max_row = 0;
     size_t device_bytes = 0;
     // arrays moved to a chosen address (spmv_hip_csr_relocate): the field points INTO `raw`, which is what gets freed
-    struct relocated { void **field; void *raw; size_t size; };
+    // (vmm: the memory came from hipMemCreate + hipMemAddressReserve + hipMemMap, `raw` is the reserved range)
+    struct relocated { void **field; void *raw; size_t size; bool vmm = false; hipMemGenericAllocationHandle_t phys = {}; size_t mapped = 0; };
     std::vector<relocated> relocs;
 };
 

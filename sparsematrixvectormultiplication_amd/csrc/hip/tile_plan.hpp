@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -63,6 +64,44 @@ struct TilePlan {
 
 namespace tile_detail {
 
+// body(0) .. body(n - 1) on n threads.  Nothing a body throws (std::bad_alloc at these sizes: a plan holds two or
+// three host copies of a 100-260 M-entry matrix) may leave its thread -- that would be std::terminate for the whole
+// process, past the C-ABI's guarded() -- so every body runs inside a catch, every started thread is joined whatever
+// happens (also when starting a later one fails), and the first exception is rethrown on the caller's thread.
+template <typename F>
+void run_threads(int n, F body) {
+    std::vector<std::exception_ptr> errors((size_t)std::max(n, 0));
+    struct Joiner {
+        std::vector<std::thread> pool;
+        ~Joiner() {
+            for (auto &th : pool)
+                if (th.joinable()) th.join();
+        }
+    } joiner;
+    joiner.pool.reserve((size_t)std::max(n, 0));
+    std::exception_ptr start_error;
+    for (int th = 0; th < n; ++th) {
+        try {
+            joiner.pool.emplace_back([&errors, &body, th] {
+                try {
+                    body(th);
+                } catch (...) {
+                    errors[(size_t)th] = std::current_exception();
+                }
+            });
+        } catch (...) {  // the thread could not be started: its share runs here, after the others have been joined
+            start_error = std::current_exception();
+            break;
+        }
+    }
+    const int started = (int)joiner.pool.size();
+    for (auto &th : joiner.pool) th.join();
+    for (int th = started; th < n; ++th) body(th);  // (throws straight to the caller)
+    (void)start_error;
+    for (auto &e : errors)
+        if (e) std::rethrow_exception(e);
+}
+
 template <typename T>
 struct Part {  // what one builder thread produced for its range of blocks
     std::vector<int> passes_per_block;
@@ -96,12 +135,9 @@ inline void sort_keys(std::vector<uint64_t> &keys, uint32_t key_top, int threads
         std::vector<size_t> at(start.begin(), start.end() - 1);
         for (uint64_t k : keys) tmp[at[(size_t)((k >> 32) >> shift)]++] = k;
     }
-    std::vector<std::thread> pool;
-    for (int th = 0; th < threads; ++th)
-        pool.emplace_back([&, th] {
-            for (int b = th; b < kBuckets; b += threads) std::sort(tmp.begin() + (long)start[(size_t)b], tmp.begin() + (long)start[(size_t)b + 1]);
-        });
-    for (auto &th : pool) th.join();
+    run_threads(threads, [&](int th) {
+        for (int b = th; b < kBuckets; b += threads) std::sort(tmp.begin() + (long)start[(size_t)b], tmp.begin() + (long)start[(size_t)b + 1]);
+    });
     keys.swap(tmp);
 }
 
@@ -302,13 +338,10 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
             if (run * threads >= total * th) cut[th++] = b + 1;
         }
     }
-    std::vector<std::thread> pool;
-    for (int th = 0; th < threads; ++th)
-        pool.emplace_back([&, th] {
-            tile_detail::build_range<T>(cut[th], cut[th + 1], plan.block_row.data(), row_begin, row_len, col, val, lmax,
-                                        pos_bits, chunk, win_cols, density, inner_threads, (uint32_t)std::max(N, 1), pack, pack ? min_pass : 0, parts[th]);
-        });
-    for (auto &th : pool) th.join();
+    tile_detail::run_threads(threads, [&](int th) {
+        tile_detail::build_range<T>(cut[th], cut[th + 1], plan.block_row.data(), row_begin, row_len, col, val, lmax,
+                                    pos_bits, chunk, win_cols, density, inner_threads, (uint32_t)std::max(N, 1), pack, pack ? min_pass : 0, parts[th]);
+    });
     size_t total_entries = 0, total_passes = 0;
     for (const auto &p : parts)
         if (p.failed) return false;
@@ -322,7 +355,7 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
     plan.tval.reserve(total_entries + kTileChunkMax);
     plan.pass_desc.reserve(total_passes);
     plan.block_pass.assign(1, 0);
-    for (const auto &p : parts) {
+    for (auto &p : parts) {
         const int base = (int)plan.tcol.size();
         for (int4 d : p.pass_desc) {
             d.x += base;
@@ -339,6 +372,7 @@ bool tile_build(int M, int N, const int *row_begin, const int *row_len, const in
         plan.rem_row.insert(plan.rem_row.end(), p.rem_row.begin(), p.rem_row.end());
         plan.rem_col.insert(plan.rem_col.end(), p.rem_col.begin(), p.rem_col.end());
         plan.rem_val.insert(plan.rem_val.end(), p.rem_val.begin(), p.rem_val.end());
+        p = tile_detail::Part<T>();  // a part's arrays are released as soon as they are merged: one copy fewer at the peak
     }
     // the kernel loads whole units past a pass's end
     plan.tcol.insert(plan.tcol.end(), (size_t)kTileChunkMax, 0);

@@ -212,9 +212,19 @@ class CsrDevice(_Handle):
 
     ARRAYS = ("row_ptr", "col", "val", "x", "y", "lcol", "lines", "ldesc4")
 
-    def relocate(self, which: str, align: int, offset: int):
-        _check(nat.lib().spmv_hip_csr_relocate(self.h, self.ARRAYS.index(which), int(align), int(offset)),
-               "spmv_hip_csr_relocate")
+    def stamp_blocks(self, warm: int = 3):
+        """(start, end, dispatch id, xcd) per x-window block of one stamped launch; times in ticks of 10 ns."""
+        n = self.info()["local_blocks"]
+        buf = np.zeros(3 * n, dtype=np.uint64)
+        _check(nat.lib().spmv_hip_csr_stamp_blocks(self.h, int(warm), buf.ctypes.data_as(C.POINTER(C.c_ulonglong))),
+               "spmv_hip_csr_stamp_blocks")
+        buf = buf.reshape(n, 3)
+        return buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64), (buf[:, 2] >> np.uint64(8)).astype(np.int64), \
+            (buf[:, 2] & np.uint64(0xf)).astype(np.int64)
+
+    def relocate(self, which: str, align: int, offset: int, vmm: bool = False):
+        fn = nat.lib().spmv_hip_csr_relocate_vmm if vmm else nat.lib().spmv_hip_csr_relocate
+        _check(fn(self.h, self.ARRAYS.index(which), int(align), int(offset)), "spmv_hip_csr_relocate")
 
     def set_x(self, x):
         x = np.ascontiguousarray(x, dtype=self.dtype)
@@ -266,6 +276,21 @@ class CsrDevice(_Handle):
                                                     int(bool(use_graph)), C.byref(lam), C.byref(ms)),
                "csr_power_iterate")
         return float(lam.value), float(ms.value)
+
+    def cg(self, b, iters, variant=CSR_AUTO, bounds=None, use_halo=False):
+        """iters steps of conjugate gradients from x0 = 0 (spmv_hip_csr_cg); returns (x, r.r history, ms)."""
+        b = np.ascontiguousarray(b, dtype=self.dtype)
+        if len(b) != self.M:
+            raise ValueError("b must have M entries")
+        x = np.zeros(self.M, dtype=self.dtype)
+        hist = np.zeros(iters + 1)
+        ms = C.c_float(0)
+        bb = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.int32)
+        _check(nat.lib().spmv_hip_csr_cg(self.h, int(variant), int(iters),
+                                         None if bb is None else bb.ctypes.data_as(nat.c_int_p), int(bool(use_halo)),
+                                         b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                                         hist.ctypes.data_as(nat.c_double_p), C.byref(ms)), "spmv_hip_csr_cg")
+        return x, hist, float(ms.value)
 
     def split_interior(self) -> dict:
         """Split the x-window blocks into interior (own range of x only) and boundary ones

@@ -32,22 +32,57 @@ def test_plan_is_refused_or_partial_where_it_should_be():
     rng = np.random.default_rng(5)
     row_ptr, col, _ = random_csr(rng, 3000, 40000, 30, 60, 0.0)       # scattered: no plan
     assert sp.csr_plan_check(3000, 40000, row_ptr, col)["local_blocks"] == 0
-    # banded + a few wild rows: plan kept, wild rows split
-    row_ptr, col, _ = banded_csr(rng, 3000, 40000, 30, 200)
-    lens = np.diff(row_ptr).astype(np.int64)
-    cols = [col[row_ptr[r]:row_ptr[r + 1]] for r in range(3000)]
-    for r in (5, 1500, 2999):
-        cols[r] = np.sort(rng.choice(40000, 500, replace=False)).astype(np.int32)
-        lens[r] = 500
-    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    st = sp.csr_plan_check(3000, 40000, rp, np.concatenate(cols))
+    # banded + a few wild rows: plan kept, wild rows split -- from 2^20 entries on (the split-row kernels are two more
+    # launches, which a smaller matrix cannot afford: it keeps its gather kernel and one launch)
+    def with_wild_rows(M, N):
+        row_ptr, col, _ = banded_csr(rng, M, N, 30, 200)
+        lens = np.diff(row_ptr).astype(np.int64)
+        cols = [col[row_ptr[r]:row_ptr[r + 1]] for r in range(M)]
+        for r in (5, M // 2, M - 1):
+            cols[r] = np.sort(rng.choice(N, 500, replace=False)).astype(np.int32)
+            lens[r] = 500
+        return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), cols
+    rp_small, cols_small = with_wild_rows(3000, 40000)
+    st_small = sp.csr_plan_check(3000, 40000, rp_small, np.concatenate(cols_small))
+    assert st_small["local_blocks"] == 0 and st_small["split_rows"] == 0 and st_small["long_rows"] == 0
+    M_big = 40000
+    rp, cols = with_wild_rows(M_big, 40000)
+    assert rp[-1] >= 1 << 20
+    st = sp.csr_plan_check(M_big, 40000, rp, np.concatenate(cols))
     assert st["local_blocks"] > 0 and st["split_rows"] == 3 and st["long_rows"] == 3
     # unsorted and repeated columns inside rows are fine
     shuffled = np.concatenate([rng.permutation(c) for c in cols])
-    st2 = sp.csr_plan_check(3000, 40000, rp, shuffled)
+    st2 = sp.csr_plan_check(M_big, 40000, rp, shuffled)
     assert st2["local_blocks"] == st["local_blocks"] and st2["lines"] == st["lines"]
     with pytest.raises(ValueError, match="outside"):
         sp.csr_plan_check(2, 2, np.array([0, 1, 2], np.int32), np.array([0, 7], np.int32))
+
+
+def test_long_rows_among_short_ones_get_blocks_of_few_rows():
+    """Circuit-shaped matrix (adder_dcop_32-size: short rows plus a few rows and columns that touch a quarter of the
+    matrix): the row-sum phase gives every row of a block the same number of lanes, so upload closes blocks around the
+    long rows (plan_check verifies that no lane adds up more than 64 entries unless its row is alone); the matrix
+    keeps its x-window plan and one launch -- no split rows."""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(32)
+    n = 1813
+    r = np.repeat(np.arange(n), 4)
+    c = np.clip(r + rng.integers(-50, 51, len(r)), 0, n - 1)
+    a = sps.csr_matrix((np.ones(len(r)), (r, c)), shape=(n, n)).tolil()
+    for k in rng.integers(0, n, 4):
+        cols = rng.integers(0, n, 450)
+        a[k, cols] = 1.0
+        a[cols, k] = 1.0
+    a = a.tocsr()
+    a.sort_indices()
+    st = sp.csr_plan_check(n, n, a.indptr.astype(np.int32), a.indices.astype(np.int32))
+    assert st["local_blocks"] > 0 and st["split_rows"] == 0 and st["long_rows"] == 0
+    assert st["local_blocks"] == st["gather_blocks"]
+    assert st["local_blocks"] >= a.nnz // 2048 + 1 + 4      # the four long rows made blocks of their own
+    # the same rows in an HLL slab: windows on the border between hacks of short and of long rows
+    from _util import coo_from_csr
+    rr, cc, vv = coo_from_csr(a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data, rng)
+    assert sp.hll_plan_check(sp.convert_to_hll(sp.PreMatrix.from_arrays(n, n, rr, cc, vv)))["gather_windows"] > 0
 
 
 def test_plan_on_the_cant_like_matrix():

@@ -106,11 +106,26 @@ LIST = [
     ("Cube_Coup_dt0", 2164760, 127206144, lambda: band(2164760, 127206144, 2500), 47.1),
 ]
 
-want = sys.argv[1:]
+want = [w for w in sys.argv[1:] if not w.startswith("--")]
 sp.hip_init(0)
-print("| stand-in for | rows | nnz | AUTO kernel | us | GFLOP/s | % of 8 TB/s | best CSR variant | its us | HLL AUTO us | HLL GFLOP/s | "
-      "reference's best CUDA GFLOP/s on the real matrix | parity |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+
+
+def rounds(dev, variants, iters, nrounds=3):
+    """mean time of every variant, measured in interleaved rounds (AUTO first in every round: whoever runs first on a cold
+    chip looked up to 6 % slower than the same kernel measured later in round 2's version of this table); the minimum of a
+    variant's round means is its time"""
+    best = {}
+    for _ in range(nrounds):
+        for name, v in variants:
+            t = float(dev.time(v, 3, iters, zero_y=False).mean())
+            best[name] = min(best.get(name, 1e9), t)
+    return best
+
+
+print("| stand-in for | rows | nnz | AUTO kernel | us | GFLOP/s | % of 8 TB/s | best CSR variant | its us | AUTO / best | HLL AUTO kernel | HLL AUTO us | "
+      "best HLL variant | its us | HLL AUTO / best | reference's best CUDA GFLOP/s on the real matrix | parity |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+worst_csr = worst_hll = 0.0
 for name, rows, nnz, make, pub in LIST:
     if want and not any(w in name for w in want):
         continue
@@ -123,29 +138,34 @@ for name, rows, nnz, make, pub in LIST:
     scale = max(np.max(np.abs(y_ref)), 1e-300)
     with sp.CsrDevice(M, N, rp, col, val) as dev:
         info = dev.info()
-        y = dev.spmv(x, sp.CSR_AUTO)
-        assert np.max(np.abs(y - y_ref)) <= 1e-10 * scale, name
-        dev.set_x(x)
-        iters = 200 if info["nz"] < 5_000_000 else 30
-        t_auto = dev.time(sp.CSR_AUTO, 5, iters, zero_y=False).mean()
-        best = ("auto", t_auto)
-        for vname, v in sp.CSR_VARIANTS.items():
-            if vname == "wave_row" and M > 4_000_000:
-                continue
+        iters = 60 if info["nz"] < 5_000_000 else 12
+        variants = [("auto", sp.CSR_AUTO)] + [(k, v) for k, v in sp.CSR_VARIANTS.items()
+                                              if not (k in ("wave_row", "thread_row") and info["nz"] > 40_000_000)]
+        for vname, v in variants:
             yv = dev.spmv(x, v)
             assert np.max(np.abs(yv - y_ref)) <= 1e-10 * scale, (name, vname)
-            dev.set_x(x)
-            t = dev.time(v, 3, max(10, iters // 4), zero_y=False).mean()
-            if t < best[1] * 0.97:
-                best = (vname, t)
+        dev.set_x(x)
+        tc = rounds(dev, variants, iters)
+        t_auto = tc["auto"]
+        best = min(tc.items(), key=lambda kv: kv[1])
         with sp.HllDevice.from_csr_device(dev) as h:
-            yh = h.spmv(x, sp.HLL_AUTO)
-            assert np.max(np.abs(yh - y_ref)) <= 1e-10 * scale, "HLL " + name
+            hinfo = h.info()
+            hvariants = [("auto", sp.HLL_AUTO)] + [(k, v) for k, v in sp.HLL_VARIANTS.items()
+                                                   if not (k == "thread_row" and hinfo["slots"] > 40_000_000)]
+            for vname, v in hvariants:
+                yh = h.spmv(x, v)
+                assert np.max(np.abs(yh - y_ref)) <= 1e-10 * scale, ("HLL", name, vname)
             h.set_x(x)
-            t_hll = h.time(sp.HLL_AUTO, 5, iters, zero_y=False).mean()
+            th = rounds(h, hvariants, iters)
+            hbest = min(th.items(), key=lambda kv: kv[1])
     kern = sp.device.CSR_STREAM_KERNELS[info["stream_kernel"]] if info["auto_variant"] == sp.CSR_STREAM else \
         [k for k, v in sp.CSR_VARIANTS.items() if v == info["auto_variant"]][0]
+    hkern = sp.device.HLL_LDS_KERNELS[hinfo["stream_kernel"]] if hinfo["auto_variant"] == sp.HLL_LDS else \
+        [k for k, v in sp.HLL_VARIANTS.items() if v == hinfo["auto_variant"]][0]
     gf = 2.0 * info["nz"] / (t_auto * 1e-3) / 1e9
+    worst_csr = max(worst_csr, t_auto / best[1])
+    worst_hll = max(worst_hll, th["auto"] / hbest[1])
     print(f"| {name} | {M} | {info['nz']} | {kern} | {t_auto * 1e3:.1f} | {gf:.0f} | {info['algo_bytes'] / t_auto / 1e6 / 80:.1f} | "
-          f"{best[0]} | {best[1] * 1e3:.1f} | {t_hll * 1e3:.1f} | {2.0 * info['nz'] / (t_hll * 1e-3) / 1e9:.0f} | "
-          f"{pub if pub else ''} | ok |", flush=True)
+          f"{best[0]} | {best[1] * 1e3:.1f} | {t_auto / best[1]:.2f} | {hkern} | {th['auto'] * 1e3:.1f} | {hbest[0]} | {hbest[1] * 1e3:.1f} | "
+          f"{th['auto'] / hbest[1]:.2f} | {pub if pub else ''} | ok |", flush=True)
+print(f"\nworst AUTO / best over the list: CSR {worst_csr:.3f}, HLL {worst_hll:.3f}")
