@@ -414,14 +414,39 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
             info = dev.info()
             ms = dev.time(sp.CSR_AUTO, warmup, max(5, steps // 4), zero_y=True)
         from sparsematrixvectormultiplication_amd.device import CSR_STREAM_KERNELS
+        t = float(ms.mean()) * 1e-3
+        kernel = CSR_STREAM_KERNELS[info["stream_kernel"]]
+        # Two ceilings for this matrix.  By HBM bytes it sits far below 8 TB/s -- because what bounds it is not the
+        # stream but the values it GATHERS (every entry of a pass that is not staged in LDS costs one request for a
+        # line out of L2).  The second roofline prices exactly that: gathered values per second against what this
+        # chip delivers for 64-different-lines gathers from an L2-resident table (spmv_hip_gather_probe, measured in
+        # this run; tools/ubench_gather.hip is its stand-alone original).
+        gathered = int(info["tile_entries"] - info["tile_staged_entries"] - info["tile_remainder_entries"]) \
+            if kernel == "csr_tile" else int(info["nz"])
+        traffic, traffic_source = measured_traffic(kernel, "power-law %dx%d fp32" % (n, n), info["stream_bytes"],
+                                                   info.get("tile_blocks", 0) or info["stream_blocks"])
+        rooflines = [{"bound": "hbm", "achieved": round(info["algo_bytes"] / t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": round(info["algo_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                      "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(info["algo_bytes"])}]
+        try:
+            peak = sp.gather_probe(4, 2 << 20, 16)
+            rooflines.append({"bound": "l2_gather", "achieved": round(gathered / t / 1e9, 2), "peak": round(peak / 1e9, 2),
+                              "unit": "G gathered values/s", "frac": round(gathered / t / peak, 4),
+                              "gathered_values_per_launch": gathered,
+                              "note": "achieved = values the product gathers (entries of passes not staged in LDS) / time of the "
+                                      "WHOLE product, staged passes and the long rows' launch included; peak = 64-different-"
+                                      "lines gathers from a 2 MiB table, 16 wavefronts per CU x 8 in flight, measured in this run"})
+        except Exception as exc:
+            rooflines.append({"bound": "l2_gather", "error": str(exc)})
         return {"workload": "power-law 2^24 x 2^24 fp32 CSR (config 5 on one GPU; no reference counterpart for fp32)",
-                "rows": n, "nnz": nnz, "algo_bytes": info["algo_bytes"],
-                "auto": {"kernel": CSR_STREAM_KERNELS[info["stream_kernel"]], "ms": round(float(ms.mean()), 4),
+                "rows": n, "nnz": nnz, "algo_bytes": info["algo_bytes"], "rooflines": rooflines,
+                "auto": {"kernel": kernel, "ms": round(float(ms.mean()), 4),
                          "gflops": round(2.0 * nnz / (ms.mean() * 1e-3) / 1e9, 1),
                          "gbps": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9, 1),
                          "pct_of_8TBs": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9 / 80.0, 2),
                          "rows_in_split_row_kernels": info["tile_split_rows"],
-                         "entries_in_tiles": info["tile_entries"], "format_bytes": info["stream_bytes"]}}
+                         "entries_in_tiles": info["tile_entries"], "entries_in_staged_passes": info["tile_staged_entries"],
+                         "format_bytes": info["stream_bytes"]}}
     M, row_ptr, col, val = synth.fem_like()
     nnz = int(row_ptr[-1])
     x = np.ones(M)
@@ -739,7 +764,13 @@ def main():
                                     "torch": "RCCL all-gatherv(y) via torch.distributed",
                                     "gloo-host": "DEBUG: all-gatherv(y) through host memory (gloo)"}[exchange],
                        "nnz_imbalance_max_over_mean": round(float(per_rank[:, 4].max() / per_rank[:, 4].mean()), 4),
-                       "device": dev_name},
+                       "device": dev_name,
+                       # where the value array lies decides which of two speeds the x-window kernel runs at (DESIGN.md,
+                       # profiles/r3_placement_*.txt): what upload's placement tuning tried and kept on rank 0
+                       "placement": {"val_address": hex(int(info.get("val_address", 0))),
+                                     "placements_timed_at_upload": int(info.get("place_tries", 0)),
+                                     "kernel_us_at_first_placement": round(float(info.get("place_first_us", 0.0)), 1),
+                                     "kernel_us_at_kept_placement": round(float(info.get("place_best_us", 0.0)), 1)}},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,

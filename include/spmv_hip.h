@@ -100,6 +100,10 @@ typedef struct {
     long long tile_long_entries;   /* CSR: entries it holds */
     long long tile_staged_cols;    /* CSR: x values the staged passes copy to LDS per SpMV (all tile plans): traffic served by L2 */
     long long tile_remainder_entries; /* CSR: ... of tile_entries, in windows too sparse for a pass: added to y by tile_remainder behind the tiles */
+    int place_tries;       /* placements of the value array that upload timed (0: not tuned -- small handle, or "place_tries" 0) */
+    float place_first_us;  /* kernel time at the placement hipMalloc gave first */
+    float place_best_us;   /* ... at the placement the handle kept */
+    unsigned long long val_address; /* where the value array lies now (placement record of a bench line) */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -122,6 +126,14 @@ int spmv_hip_device_state(char *buf, size_t len);
  * non-temporal loads, 2048-thread-blocks grid-stride; mean / min event time per launch in ms.  What this box's HBM
  * gives a pure stream right now: the yardstick beside every kernel time in a bench line. */
 int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min);
+/* the same read-only stream over device memory the caller names (16-byte aligned) */
+int spmv_hip_stream_probe_at(const void *dptr, size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min);
+/* Gather probe: values per second the chip delivers when every lane of every gather wave-instruction reads a different
+ * random line of a table of `table_bytes` (rounded down to a power of two of elements; <= 2 MiB: L2 resident on every
+ * XCD), `waves_per_cu` wavefronts per CU with 8 independent gathers in flight each.  The ceiling of a gather-bound
+ * kernel (csr_tile's gather passes, the gather stream kernels on scattered columns), as the stream probe is the
+ * ceiling of a streaming one. */
+int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu, double *values_per_s);
 /* Kernel tuning knobs, for A/B measurements (defaults are the measured best; also settable through the
  * environment, SPMV_TUNING="key=value,...", read by spmv_hip_init):
  *   read at upload
@@ -147,6 +159,8 @@ int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float *ms_mean, f
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
+ *                     "tile_plan_on_device" 1 | 0 the plan is built by kernels from the CSR arrays in HBM (round 3) or by host
+ *                     threads; the two builders give the same bytes;
  *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 32 KiB window and
  *                     staged, keys in the column words, kernel instantiation without gather code) unless its passes
  *                     would average fewer than 256 entries; 0: always the plan with gather passes
@@ -155,6 +169,11 @@ int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float *ms_mean, f
  *                     csr_stream) | 5 x-window | 6 csr_tile |
  *                     0 csr_stream; only in a `make EXPERIMENTAL=1` build: 1 row walk | 2 persistent pipe |
  *                     3 persistent row walk | 4 loader/consumer ring | 10..17 ablation probes (measurement only)
+ *     "place_tries"   (3) read at upload: how many other placements of the value array a handle that streams >= 128 MiB of
+ *                     values tries (a fresh allocation each, the kernel timed 2 + 6 launches on it), keeping the fastest.
+ *                     Round 3 found the x-window kernel's time on the headline matrix to depend on WHERE the values lie:
+ *                     the same matrix runs in 182-187 or in 199-205 us, deterministically per address
+ *                     (profiles/r3_placement_*.txt); 0 keeps what hipMalloc gave first
  *     "stream_nt" 0/1, "local_nt" -1 (auto) / 0 / 1   non-temporal hint on the streamed arrays
  *     "stream_xcd"    blocks per XCD run: 0 default (16 for the x-window kernels, dispatch order otherwise),
  *                     -1 one contiguous eighth per XCD, n > 0 runs of n
@@ -198,6 +217,11 @@ int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, const int *co
  * CU), rows per block the kernel is launched for, row blocks, streams (workgroups), passes, rows of the tallest
  * block, work items of the long rows' plan, entries in the ordinary tiles. */
 int spmv_hip_csr_tile_auto_plan(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, long long *stats);
+/* Digests of the arrays of a handle's csr_tile plans (the tests' way of saying "the plan built on the device is the plan
+ * the host builder makes"): digest[2 k] = elements, digest[2 k + 1] = a hash of the bytes of array k, 22 arrays (entry
+ * arrays, pass descriptors, stream tables, remainder, the long rows' plan); digest has 44 entries. */
+int spmv_hip_csr_tile_digest(const spmv_csr_dev *m, unsigned long long *digest);
+int spmv_hip_hll_tile_digest(const spmv_hll_dev *m, unsigned long long *digest);
 /* COO triplets (0-based, any order) -> a CSR handle, built ON THE DEVICE (upload of the
  * triplets, one stable radix sort by (row, column), row pointers and the x-window plan by kernels).  Same
  * matrix as convert_in_csr + spmv_hip_csr_upload_matrix; entries that repeat one (row, column) keep file

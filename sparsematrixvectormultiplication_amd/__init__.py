@@ -15,4 +15,4 @@ from .host import (HACK_SIZE, ITERATION_SKIP, CsrHost, HllHost, PreMatrix,  # no
 from .device import (CSR_AUTO, CSR_STREAM, CSR_SUBWAVE, CSR_THREAD_ROW, CSR_VARIANTS,  # noqa: F401
                      CSR_WAVE_ROW, HLL_AUTO, HLL_LDS, HLL_SUBWAVE, HLL_THREAD_ROW, HLL_VARIANTS,
                      CsrDevice, HllDevice, SpmvHipError, device_count, device_name, flush_cache,
-                     hip_init, hip_stream, hip_sync, box_state, stream_probe, set_tuning)
+                     hip_init, hip_stream, hip_sync, box_state, stream_probe, stream_probe_at, gather_probe, set_tuning)

@@ -54,7 +54,9 @@ class DevInfo(C.Structure):
                 ("tile_blocks", C.c_int), ("tile_passes", C.c_int), ("tile_split_rows", C.c_int),
                 ("tile_entries", C.c_longlong), ("tile_staged_entries", C.c_longlong),
                 ("tile_long_rows", C.c_int), ("tile_long_items", C.c_int), ("tile_long_entries", C.c_longlong),
-                ("tile_staged_cols", C.c_longlong), ("tile_remainder_entries", C.c_longlong)]
+                ("tile_staged_cols", C.c_longlong), ("tile_remainder_entries", C.c_longlong),
+                ("place_tries", C.c_int), ("place_first_us", C.c_float), ("place_best_us", C.c_float),
+                ("val_address", C.c_ulonglong)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -147,6 +149,10 @@ _PROTOTYPES = {
     "spmv_hip_flush_cache": (C.c_int, [C.c_size_t]),
     "spmv_hip_device_state": (C.c_int, [C.c_char_p, C.c_size_t]),
     "spmv_hip_stream_probe": (C.c_int, [C.c_size_t, C.c_int, C.c_int, c_float_p, c_float_p]),
+    "spmv_hip_stream_probe_at": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, c_float_p, c_float_p]),
+    "spmv_hip_gather_probe": (C.c_int, [C.c_int, C.c_size_t, C.c_int, c_double_p]),
+    "spmv_hip_csr_tile_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "spmv_hip_hll_tile_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "spmv_hip_csr_addresses": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "spmv_hip_csr_stamp_blocks": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]),
     "spmv_hip_csr_relocate": (C.c_int, [C.c_void_p, C.c_int, C.c_ulonglong, C.c_ulonglong]),

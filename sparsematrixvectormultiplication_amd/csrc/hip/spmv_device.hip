@@ -35,6 +35,33 @@ __global__ __launch_bounds__(kBlock) void stream_probe_kernel(const uint4 *__res
     if (acc == 0x9e3779b9u) sink[blockIdx.x] = acc;  // never true on the zeroed buffer: keeps the loads alive
 }
 
+// What a gathered value costs when every lane of a wave-instruction hits a different line that lives in L2: each
+// wavefront issues 8 independent gathers per trip from a table of `mask + 1` elements (the pattern keeps its shape
+// and moves over the table).  tools/ubench_gather.hip is the stand-alone original of this probe.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_probe_kernel(const T *__restrict__ x, const unsigned *__restrict__ idx,
+                                                              T *__restrict__ out, int iters, unsigned mask) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    unsigned rot = wave * 977u;
+    T acc = 0;
+    unsigned my[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) my[j] = idx[j * 64 + lane];
+    for (int it = 0; it < iters; ++it) {
+        T v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned off = ((my[j] + rot) & mask) * (unsigned)sizeof(T);
+            v[j] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(x) + off);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j];
+        rot += 4099u * 16u;
+    }
+    if (acc == T(12345.678)) out[0] = acc;  // never true on the zeroed table: keeps the loads alive
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ state
@@ -61,6 +88,8 @@ int g_stream_tile = -1;
 int g_tile_rows = 0;
 int g_tile_lmax = 1024;
 int g_tile_density = 4;
+int g_tile_plan_on_device = 1;
+int g_place_tries = 3;
 int g_tile_probe = 0;
 int g_skew_rows = 1;
 int g_tile_fit = 1;
@@ -220,6 +249,11 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_skew_rows = value != 0;
     } else if (!strcmp(key, "tile_probe")) {
         g_tile_probe = value & 15;
+    } else if (!strcmp(key, "place_tries")) {
+        if (value < 0 || value > 16) return fail("set_tuning: place_tries must be 0..16");
+        g_place_tries = value;  // takes effect at the next upload
+    } else if (!strcmp(key, "tile_plan_on_device")) {
+        g_tile_plan_on_device = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "tile_density")) {
         if (value < 0 || value > 4096) return fail("set_tuning: tile_density must be 0 (never stage) .. 4096");
         g_tile_density = value;
@@ -305,18 +339,7 @@ extern "C" int spmv_hip_device_state(char *buf, size_t len) {
     return 0;
 }
 
-extern "C" int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min) {
-    if (need_device()) return -1;
-    if (iters <= 0 || iters > 1000 || warmup < 0) return fail("stream_probe: iters must be 1..1000");
-    if (bytes < (1u << 20)) bytes = 1u << 20;
-    if (bytes > g_flush_bytes) {
-        if (g_flush_buf) HIP_TRY(hipFree(g_flush_buf));
-        g_flush_buf = nullptr;
-        g_flush_bytes = 0;
-        HIP_TRY(hipMalloc(&g_flush_buf, bytes));
-        HIP_TRY(hipMemset(g_flush_buf, 0, bytes));
-        g_flush_bytes = bytes;
-    }
+static int stream_probe_run(const void *buf, size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min) {
     unsigned *sink = nullptr;
     const int grid = g_num_cus * 8;
     HIP_TRY(hipMalloc((void **)&sink, (size_t)grid * sizeof(unsigned)));
@@ -324,7 +347,7 @@ extern "C" int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float 
     const int rc = time_loop(warmup, iters, ms.data(),
                              [&]() {
                                  hipLaunchKernelGGL(stream_probe_kernel, dim3(grid), dim3(kBlock), 0, g_stream,
-                                                    (const uint4 *)g_flush_buf, bytes / 16, sink);
+                                                    (const uint4 *)buf, bytes / 16, sink);
                                  hipError_t e = hipGetLastError();
                                  return e == hipSuccess ? 0 : fail("stream_probe launch: %s", hipGetErrorString(e));
                              },
@@ -340,6 +363,84 @@ extern "C" int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float 
     if (ms_mean) *ms_mean = (float)(sum / iters);
     if (ms_min) *ms_min = mn;
     return 0;
+}
+
+extern "C" int spmv_hip_stream_probe(size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min) {
+    if (need_device()) return -1;
+    if (iters <= 0 || iters > 1000 || warmup < 0) return fail("stream_probe: iters must be 1..1000");
+    if (bytes < (1u << 20)) bytes = 1u << 20;
+    if (bytes > g_flush_bytes) {
+        if (g_flush_buf) HIP_TRY(hipFree(g_flush_buf));
+        g_flush_buf = nullptr;
+        g_flush_bytes = 0;
+        HIP_TRY(hipMalloc(&g_flush_buf, bytes));
+        HIP_TRY(hipMemset(g_flush_buf, 0, bytes));
+        g_flush_bytes = bytes;
+    }
+    return stream_probe_run(g_flush_buf, bytes, warmup, iters, ms_mean, ms_min);
+}
+
+// the same probe over memory the caller names (16-byte aligned): what THIS allocation gives a pure stream
+extern "C" int spmv_hip_stream_probe_at(const void *dptr, size_t bytes, int warmup, int iters, float *ms_mean, float *ms_min) {
+    if (need_device()) return -1;
+    if (!dptr || ((uintptr_t)dptr & 15) || bytes < 16 || iters <= 0 || iters > 1000 || warmup < 0)
+        return fail("stream_probe_at: bad arguments");
+    return stream_probe_run(dptr, bytes, warmup, iters, ms_mean, ms_min);
+}
+
+extern "C" int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu, double *values_per_s) {
+    if (need_device()) return -1;
+    if ((value_bytes != 4 && value_bytes != 8) || !values_per_s || waves_per_cu < 4 || waves_per_cu > 32 || (waves_per_cu & 3))
+        return fail("gather_probe: value_bytes 4 | 8, waves_per_cu a multiple of 4 in 4..32");
+    size_t elems = 1;
+    while (elems * 2 * (size_t)value_bytes <= table_bytes) elems *= 2;  // a power of two of elements
+    if (elems < 4096 || elems * (size_t)value_bytes > ((size_t)1 << 31)) return fail("gather_probe: table of 32 KiB .. 2 GiB");
+    void *table = nullptr, *out = nullptr;
+    unsigned *idx = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    do {
+        // 64 different random lines per wave-instruction (a fixed xorshift pattern)
+        std::vector<unsigned> pattern(8 * 64);
+        unsigned state = 2463534242u;
+        for (auto &v : pattern) {
+            state ^= state << 13;
+            state ^= state >> 17;
+            state ^= state << 5;
+            v = state;
+        }
+        hipError_t e = hipMalloc(&table, elems * (size_t)value_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&idx, pattern.size() * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMalloc(&out, 64);
+        if (e == hipSuccess) e = hipMemsetAsync(table, 0, elems * (size_t)value_bytes, g_stream);
+        if (e == hipSuccess) e = hipMemcpy(idx, pattern.data(), pattern.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e != hipSuccess) { rc = fail("gather_probe: setup failed: %s", hipGetErrorString(e)); break; }
+        const int iters = 1000, blocks = g_num_cus * waves_per_cu / 4;
+        const unsigned mask = (unsigned)elems - 1;
+        auto launch = [&](int n) {
+            if (value_bytes == 8)
+                hipLaunchKernelGGL((gather_probe_kernel<double>), dim3(blocks), dim3(kBlock), 0, g_stream, (const double *)table, idx, (double *)out, n, mask);
+            else
+                hipLaunchKernelGGL((gather_probe_kernel<float>), dim3(blocks), dim3(kBlock), 0, g_stream, (const float *)table, idx, (float *)out, n, mask);
+        };
+        launch(50);
+        e = hipEventRecord(e0, g_stream);
+        launch(iters);
+        if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess || ms <= 0) { rc = fail("gather_probe: run failed: %s", hipGetErrorString(e)); break; }
+        *values_per_s = (double)iters * 8.0 * 64.0 * (double)waves_per_cu * (double)g_num_cus / (ms * 1e-3);
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(table);
+    (void)hipFree(idx);
+    (void)hipFree(out);
+    return rc;
 }
 
 extern "C" int spmv_hip_malloc(void **dptr, size_t bytes) {

@@ -227,7 +227,9 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
         const long long mean = std::max<long long>(1, off[H] / total_rows);
         for (int h = 0; h < H && !skewed; ++h) skewed = mz[(size_t)h] > 16 * mean;
     }
-    if (!rc && !skewed && m->local_blocks == 0 && ja_host && as_host && true_slots > 0 && off[H] < 0x7fffffffLL) {
+    // (the plan is built on the device from the slab there; the host copies, where the caller has them, are the fallback)
+    const bool slab_at_hand = (ja_host && as_host) || (g_tile_plan_on_device && m->JA && m->AS);
+    if (!rc && !skewed && m->local_blocks == 0 && slab_at_hand && true_slots > 0 && off[H] < 0x7fffffffLL) {
         std::vector<int> row_begin((size_t)total_rows), row_len((size_t)total_rows);
         for (int r = 0; r < total_rows; ++r) {
             const int h = r / kHack;
@@ -235,7 +237,7 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
             row_begin[(size_t)r] = (int)(off[(size_t)h] + (long long)(r % kHack) * mz[(size_t)h]);
         }
         rc = csr_tiles_from_rows_f64(total_rows, m->M_total, row0, N, row_begin.data(), row_len.data(), true_slots, ja_host,
-                                     as_host, &m->tiles);
+                                     as_host, &m->tiles, m->JA, m->AS);
         if (!rc && m->tiles) m->device_bytes += m->tiles->device_bytes;
     }
     const double mean = total_rows ? (double)true_slots / total_rows : 0.0;
@@ -244,6 +246,63 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
 }
 
 }  // namespace
+
+// The HLL twin of csr_tune_placement (spmv_csr.hip): a slab whose AS array is large enough for its placement to
+// matter times its own kernel on a few fresh allocations of AS and keeps the fastest.
+static void hll_tune_placement(spmv_hll_dev *m) {
+    size_t bytes = 0;
+    if (g_place_tries <= 0 || (size_t)m->slots * sizeof(double) < ((size_t)128 << 20) || !m->AS) return;
+    if (hipMemPtrGetInfo(m->AS, &bytes) != hipSuccess || bytes < (size_t)m->slots * sizeof(double)) return;
+    if (m->local_blocks == 0 && m->tiles) return;  // csr_tile over the slab's rows streams its own re-ordered copy
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return;
+    }
+    auto measure = [&](float &us) {
+        for (int i = 0; i < 2; ++i)
+            if (hll_launch(m, SPMV_HLL_AUTO, m->x, m->y, g_stream)) return -1;
+        hipError_t e = hipEventRecord(e0, g_stream);
+        for (int i = 0; i < 6 && e == hipSuccess; ++i)
+            if (hll_launch(m, SPMV_HLL_AUTO, m->x, m->y, g_stream)) return -1;
+        if (e == hipSuccess) e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) return -1;
+        us = ms * 1e3f / 6.0f;
+        return 0;
+    };
+    double *first = m->AS, *best = m->AS;
+    float best_us = 0;
+    std::vector<double *> others;
+    int rc = measure(best_us);
+    m->place_first_us = best_us;
+    m->place_tries = 1;
+    for (int t = 0; t < g_place_tries && !rc; ++t) {
+        double *p = nullptr;
+        if (hipMalloc((void **)&p, bytes) != hipSuccess) break;
+        others.push_back(p);
+        if (hipMemcpy(p, first, bytes, hipMemcpyDeviceToDevice) != hipSuccess) break;
+        m->AS = p;
+        float us = 0;
+        rc = measure(us);
+        if (rc) break;
+        ++m->place_tries;
+        if (us < best_us * 0.985f) {
+            best = p;
+            best_us = us;
+        }
+        if (best_us < m->place_first_us * 0.94f) break;
+    }
+    m->AS = best;
+    m->place_best_us = best_us;
+    if (best != first) (void)hipFree(first);
+    for (double *p : others)
+        if (p != best) (void)hipFree(p);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
 
 // Host-only self-check of what HLL upload precomputes (flat slab offsets, workgroup windows, the
 // x-window plan); needs no device.  stats (optional, 4 ints): gather windows, x-window windows
@@ -472,6 +531,7 @@ static int spmv_hip_hll_upload_part_body(const HLLMatrix *hll, int total_rows, i
         spmv_hip_hll_free(m);
         return -1;
     }
+    hll_tune_placement(m);
     *out = m;
     return 0;
 }
@@ -543,8 +603,10 @@ static int spmv_hip_hll_from_csr_body(const spmv_csr_dev *csr, spmv_hll_dev **ou
             ja_host.resize((size_t)S);
             e = hipMemcpy(ja_host.data(), m->JA, (size_t)S * sizeof(int), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { rc = fail("hll_from_csr: JA download failed: %s", hipGetErrorString(e)); break; }
-            // (the values too: a slab without an x-window plan may get the tile plan, built on the host)
-            if (g_stream_tile != 0 && (g_stream_tile == 1 || (long long)M >= kTileMinRows || S >= kTileMidEntries)) {
+            // (the values too when the tile plan of a slab without an x-window plan is to be built on the HOST:
+            // "tile_plan_on_device" 0; the device builder reads the slab where it is)
+            if (!g_tile_plan_on_device && g_stream_tile != 0 &&
+                (g_stream_tile == 1 || (long long)M >= kTileMinRows || S >= kTileMidEntries)) {
                 as_host.resize((size_t)S);
                 e = hipMemcpy(as_host.data(), m->AS, (size_t)S * sizeof(double), hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { rc = fail("hll_from_csr: AS download failed: %s", hipGetErrorString(e)); break; }
@@ -560,6 +622,7 @@ static int spmv_hip_hll_from_csr_body(const spmv_csr_dev *csr, spmv_hll_dev **ou
         spmv_hip_hll_free(m);
         return -1;
     }
+    hll_tune_placement(m);
     *out = m;
     return 0;
 }
@@ -602,6 +665,16 @@ extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
     delete m;
 }
 
+// the digest of the tile plan over the slab's rows (tests); all zeros without one
+extern "C" int spmv_hip_hll_tile_digest(const spmv_hll_dev *m, unsigned long long *out) {
+    if (!m || !out) return fail("hll_tile_digest: NULL argument");
+    if (!m->tiles) {
+        memset(out, 0, 44 * sizeof(unsigned long long));
+        return 0;
+    }
+    return guarded("hll_tile_digest", [&] { return csr_tile_digest(m->tiles, out); });
+}
+
 extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     if (!m || !out) return fail("hll_info: NULL argument");
     memset(out, 0, sizeof *out);
@@ -619,6 +692,10 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     out->algo_bytes = m->slots * 12 + 12LL * m->hacks + 8LL * ((long long)m->M + m->N);
     out->device_bytes = (long long)m->device_bytes;
     out->local_blocks = m->local_blocks;
+    out->place_tries = m->place_tries;
+    out->place_first_us = m->place_first_us;
+    out->place_best_us = m->place_best_us;
+    out->val_address = (unsigned long long)(uintptr_t)m->AS;
     out->stream_kernel = m->local_blocks > 0 ? 1 : m->tiles ? 2 : 0;
     if (m->tiles) {
         spmv_dev_info t;

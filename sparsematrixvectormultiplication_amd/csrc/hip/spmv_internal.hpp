@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -62,6 +63,8 @@ extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keep
 extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile plan of their own (compacted rows, work items, slabs)
 extern int g_tile_pack;       // 1: passes that can be staged store head | row | column offset in one 32-bit word (no key read)
 extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
+extern int g_place_tries;     // other placements of the value array upload tries for large handles (0: none)
+extern int g_tile_plan_on_device;  // 1: the csr_tile plan is built by kernels (tile_plan_device.hpp), 0: by host threads (tile_plan.hpp)
 extern int g_num_cus;
 extern int g_probe_mask;      // csr_probe: table size - 1 (entries) of the folded gather
 
@@ -108,6 +111,30 @@ int upload_array(T **dptr, const T *host, size_t count, size_t pad) {
     if (pad) HIP_TRY(hipMemset(*dptr + count, 0, pad * sizeof(T)));
     return 0;
 }
+
+// SPMV_TRACE_UPLOAD=1: where an upload spends its time, phase by phase, on stderr (tools/time_upload.py).
+// mark(name) closes the phase that began at the previous mark (the device is synchronised first, so device work is
+// charged to the phase that launched it).
+struct UploadTrace {
+    bool on;
+    double t_last;
+    const char *who;
+    static double now() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
+    explicit UploadTrace(const char *name) : on(getenv("SPMV_TRACE_UPLOAD") != nullptr), t_last(0), who(name) {
+        if (on) t_last = now();
+    }
+    void mark(const char *phase) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const double t = now();
+        fprintf(stderr, "[upload trace] %-18s %-34s %8.1f ms\n", who, phase, (t - t_last) * 1e3);
+        t_last = t;
+    }
+};
 
 inline int pow2_floor(int v) {
     int p = 1;
@@ -208,6 +235,8 @@ struct spmv_csr_dev {
     int auto_variant = SPMV_CSR_STREAM;
     int max_row = 0;
     size_t device_bytes = 0;
+    int place_tries = 0;  // placement tuning at upload (csr_tune_placement): placements timed, first / kept time
+    float place_first_us = 0, place_best_us = 0;
     // arrays moved to a chosen address (spmv_hip_csr_relocate): the field points INTO `raw`, which is what gets freed
     // (vmm: the memory came from hipMemCreate + hipMemAddressReserve + hipMemMap, `raw` is the reserved range)
     struct relocated { void **field; void *raw; size_t size; bool vmm = false; hipMemGenericAllocationHandle_t phys = {}; size_t mapped = 0; };
@@ -240,6 +269,8 @@ struct spmv_hll_dev {
     int lanes_per_row = 8;
     int auto_variant = SPMV_HLL_LDS;
     size_t device_bytes = 0;
+    int place_tries = 0;  // placement tuning at upload (hll_tune_placement)
+    float place_first_us = 0, place_best_us = 0;
 };
 
 // Blocks for csr_stream_local: csr_build_blocks' cut with one more limit, the number of
@@ -263,9 +294,13 @@ struct LocalPlan {
 int csr_adopt_f64(int M, int N, const int *row_ptr_host, int *d_col, double *d_val, spmv_csr_dev **out);
 // spmv_csr.hip: tile plans alone for rows given as (first entry, length) over host arrays (an HLL slab's rows);
 // *out = NULL when the rows get no plan
+// (col / val: host copies of the rows' arrays, or NULL when d_col / d_val -- the same arrays on the device -- are given
+// and the plan is built there)
 int csr_tiles_from_rows_f64(int M_local, int M_total, int row0, int N, const int *row_begin, const int *row_len,
-                            long long entries, const int *col, const double *val, spmv_csr_dev **out);
+                            long long entries, const int *col, const double *val, spmv_csr_dev **out,
+                            const int *d_col = nullptr, const double *d_val = nullptr);
 
+int csr_tile_digest(const spmv_csr_dev *m, unsigned long long *out);  // spmv_csr.hip: see spmv_hip_csr_tile_digest
 // launchers the timing / exchange code calls across translation units
 int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s);
 // part 0: the interior x-window blocks only; part 1: everything else (boundary blocks, split rows)

@@ -68,6 +68,22 @@ def stream_probe(nbytes: int = 1 << 30, warmup: int = 3, iters: int = 10):
     return float(mean.value), float(mn.value)
 
 
+def stream_probe_at(dptr: int, nbytes: int, warmup: int = 2, iters: int = 8):
+    """(mean, min) ms of the read-only stream over [dptr, dptr + nbytes) (spmv_hip_stream_probe_at)."""
+    mean, mn = C.c_float(0), C.c_float(0)
+    _check(nat.lib().spmv_hip_stream_probe_at(C.c_void_p(dptr), int(nbytes), int(warmup), int(iters), C.byref(mean),
+                                              C.byref(mn)), "spmv_hip_stream_probe_at")
+    return float(mean.value), float(mn.value)
+
+
+def gather_probe(value_bytes: int = 4, table_bytes: int = 2 << 20, waves_per_cu: int = 16) -> float:
+    """values / s of 64-different-lines gathers from an L2-resident table (spmv_hip_gather_probe)."""
+    out = C.c_double(0)
+    _check(nat.lib().spmv_hip_gather_probe(int(value_bytes), int(table_bytes), int(waves_per_cu), C.byref(out)),
+           "spmv_hip_gather_probe")
+    return float(out.value)
+
+
 def _read(path, limit=400):
     try:
         with open(path) as fh:
@@ -211,6 +227,12 @@ class CsrDevice(_Handle):
         return dict(zip(("row_ptr", "col", "val", "x", "y", "lcol", "lines", "ldesc4"), (int(v) for v in out)))
 
     ARRAYS = ("row_ptr", "col", "val", "x", "y", "lcol", "lines", "ldesc4")
+
+    def tile_digest(self):
+        """(elements, hash) of each of the 22 arrays of the handle's tile plans (spmv_hip_csr_tile_digest)."""
+        out = (C.c_ulonglong * 44)()
+        _check(nat.lib().spmv_hip_csr_tile_digest(self.h, out), "spmv_hip_csr_tile_digest")
+        return [(int(out[2 * k]), int(out[2 * k + 1])) for k in range(22)]
 
     def stamp_blocks(self, warm: int = 3):
         """(start, end, dispatch id, xcd) per x-window block of one stamped launch; times in ticks of 10 ns."""
@@ -371,6 +393,11 @@ class HllDevice(_Handle):
 
     x_ptr = property(lambda s: nat.lib().spmv_hip_hll_x_ptr(s.h) or 0)
     y_ptr = property(lambda s: nat.lib().spmv_hip_hll_y_ptr(s.h) or 0)
+
+    def tile_digest(self):
+        out = (C.c_ulonglong * 44)()
+        _check(nat.lib().spmv_hip_hll_tile_digest(self.h, out), "spmv_hip_hll_tile_digest")
+        return [(int(out[2 * k]), int(out[2 * k + 1])) for k in range(22)]
 
     def download(self):
         """(hack_off, maxnz, JA, AS) of the flat device slab."""

@@ -551,10 +551,11 @@ def test_x_window_plan_is_refused_for_scattered_columns(gpu, oracle):
 def test_x_window_plan_keeps_going_past_a_few_scattered_rows(gpu, oracle):
     """A banded matrix with a handful of rows whose columns are spread over all of x (each
     needs more lines than a block may list): those rows are handed to the split-row kernels,
-    the rest keeps the x-window plan; fp64 and fp32."""
+    the rest keeps the x-window plan; fp64 and fp32.  (From 2^20 entries on: a smaller matrix keeps
+    one launch of its gather kernel instead of paying two more for the split rows.)"""
     from _util import banded_csr
     rng = np.random.default_rng(57)
-    M, N = 6000, 40000
+    M, N = 36000, 40000
     for dtype in (np.float64, np.float32):
         row_ptr, col, val = banded_csr(rng, M, N, 30, 200, 0.02, dtype=dtype)
         lens = np.diff(row_ptr).astype(np.int64)
@@ -571,6 +572,7 @@ def test_x_window_plan_keeps_going_past_a_few_scattered_rows(gpu, oracle):
         rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         c2, v2 = np.concatenate(cols).astype(np.int32), np.concatenate(vals).astype(dtype)
         x = rng.uniform(-1, 1, N).astype(dtype)
+        assert rp[-1] >= 1 << 20
         with sp.CsrDevice(M, N, rp, c2, v2) as dev:
             info = dev.info()
             assert info["local_blocks"] > 0 and info["long_rows"] == len(wild)
@@ -581,6 +583,32 @@ def test_x_window_plan_keeps_going_past_a_few_scattered_rows(gpu, oracle):
                 else:
                     ref = oracle.csr_f32_accum64(rp, c2, v2, x)
                     assert np.max(np.abs(y.astype(np.float64) - ref)) / np.max(np.abs(ref)) <= FP32_NORMWISE_RTOL
+
+
+def test_small_matrix_with_scattered_rows_keeps_one_launch(gpu, oracle):
+    """The same shape below 2^20 entries: no x-window plan with split rows (two more launches would cost more than the
+    whole product); the gather kernel takes everything, and the blocks around the long rows hold few rows."""
+    from _util import banded_csr
+    rng = np.random.default_rng(58)
+    M, N = 3000, 40000
+    row_ptr, col, val = banded_csr(rng, M, N, 30, 200, 0.02)
+    lens = np.diff(row_ptr).astype(np.int64)
+    cols, vals = [], []
+    for r in range(M):
+        if r in (3, 1500, M - 2):
+            cols.append(np.sort(rng.choice(N, 600, replace=False)).astype(np.int32))
+            vals.append(rng.uniform(-1, 1, 600))
+            lens[r] = 600
+        else:
+            cols.append(col[row_ptr[r]:row_ptr[r + 1]]); vals.append(val[row_ptr[r]:row_ptr[r + 1]])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    c2, v2 = np.concatenate(cols).astype(np.int32), np.concatenate(vals)
+    x = rng.uniform(-1, 1, N)
+    with sp.CsrDevice(M, N, rp, c2, v2) as dev:
+        info = dev.info()
+        assert info["local_blocks"] == 0 and info["long_rows"] == 0
+        for vname, variant in CSR_V:
+            assert_parity(dev.spmv(x, variant), oracle.csr_serial(rp, c2, v2, x), rp, c2, v2, x, what=f"small scattered {vname}")
 
 
 def test_x_window_kernel_with_long_rows_row_blocks_and_foreign_x(gpu, oracle):
@@ -832,20 +860,29 @@ def test_conjugate_gradients_match_the_oracle_loop(gpu, oracle):
     row_ptr, col, val = spd_banded(rng, n, 7, 60)
     x_true = rng.uniform(-1, 1, n)
     b = oracle.csr_serial(row_ptr, col, val, x_true)
-    iters = 12
+    iters = 25
     x_ref, hist_ref = cg_with(lambda v: oracle.csr_serial(row_ptr, col, val, v), b, iters)
     assert hist_ref[-1] < 1e-6 * hist_ref[0]          # the reference loop itself converges on this matrix
+    assert np.max(np.abs(x_ref - x_true)) <= 1e-3 * np.max(np.abs(x_true))
     with sp.CsrDevice(n, n, row_ptr, col, val) as dev:
+        # (dot products are summed in another order than numpy's: the difference is rounding, and a Krylov recurrence
+        # carries it along -- 1e-10 after a few steps, 1e-8 after 25)
+        x5, hist5, _ = dev.cg(b, 5)
+        x_ref5, hist_ref5 = cg_with(lambda v: oracle.csr_serial(row_ptr, col, val, v), b, 5)
+        assert np.max(np.abs(x5 - x_ref5)) <= 1e-10 * np.max(np.abs(x_ref5))
+        assert np.all(np.abs(hist5 - hist_ref5) <= 1e-10 * hist_ref5[0])
         x, hist, ms = dev.cg(b, iters)
         assert ms > 0 and hist[0] == pytest.approx(hist_ref[0], rel=1e-13)
-        assert np.max(np.abs(x - x_ref)) <= 1e-10 * np.max(np.abs(x_ref))
-        assert np.all(np.abs(hist - hist_ref) <= 1e-8 * hist_ref[0] + 1e-6 * hist_ref)
+        assert np.max(np.abs(x - x_ref)) <= 1e-7 * np.max(np.abs(x_ref))
+        assert np.all(np.abs(hist - hist_ref) <= 1e-8 * hist_ref[0] + 1e-4 * hist_ref)
         assert np.max(np.abs(x - x_true)) <= 1e-3 * np.max(np.abs(x_true))   # and towards the solution
+        resid = b - oracle.csr_serial(row_ptr, col, val, x)
+        assert float(resid @ resid) <= 4.0 * hist[-1] + 1e-20 * hist[0]     # the recurrence's residual is the true one
         x2, hist2, _ = dev.cg(b, iters)
         assert x2.tobytes() == x.tobytes() and hist2.tobytes() == hist.tobytes()
         for variant in (sp.CSR_SUBWAVE, sp.CSR_WAVE_ROW, sp.CSR_THREAD_ROW):
             xv, _, _ = dev.cg(b, iters, variant)
-            assert np.max(np.abs(xv - x_ref)) <= 1e-10 * np.max(np.abs(x_ref))
+            assert np.max(np.abs(xv - x_ref)) <= 1e-7 * np.max(np.abs(x_ref))
         comm = NativeComm(0, 1, lambda ident: ident)
         try:
             bounds = np.array([0, n], np.int32)

@@ -38,7 +38,7 @@ class tuned:
     def __exit__(self, *exc):
         defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 4, "stream_kind": -1,
                     "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1, "tile_places": 0,
-                    "tile_streams": 1, "tile_fit": 1}
+                    "tile_streams": 1, "tile_fit": 1, "tile_plan_on_device": 1, "place_tries": 3, "tile_min_pass": 256}
         for k in self.kv:
             set_tuning(k, defaults[k])
 
@@ -180,6 +180,93 @@ def test_tile_kernel_skewed_rows_sub_runs_and_split_rows(gpu, oracle, dtype):
                 else:            # ... or the split-row kernels
                     assert info["tile_split_rows"] == int((lens > lmax).sum()) > 0 and info["tile_long_rows"] == 0
                 check(dev, x, y_ref, rp, col, val, dtype, f"skewed lmax={lmax} balance={balance} long={long_plan}")
+
+
+DIGEST_ARRAYS = ("tcol", "tkey", "tval", "pass", "stream_pass", "block_row", "stream_block", "sblock_rows", "rem_row", "rem_ptr",
+                 "rem_col", "rem_val", "lt.tcol", "lt.tkey", "lt.tval", "lt.pass", "lt.block_row", "lt.block_pass", "lt.work",
+                 "lt.item_first", "lt.row_map", "lt.block_of_row")
+
+
+def digests_by_builder(make_handle):
+    """the handle's tile-plan digest with the plan built by host threads and by the device kernels"""
+    out = []
+    for on_device in (0, 1):
+        with tuned(tile_plan_on_device=on_device):
+            with make_handle() as dev:
+                out.append((dev.tile_digest(), dev.info()))
+    return out
+
+
+def assert_same_plan(host, device, what):
+    (dh, ih), (dd, idv) = host, device
+    for name, a, b in zip(DIGEST_ARRAYS, dh, dd):
+        assert a == b, f"{what}: array {name} differs between the host-built and the device-built plan: {a} vs {b}"
+    for key in ("tile_blocks", "tile_passes", "tile_entries", "tile_staged_entries", "tile_staged_cols", "tile_remainder_entries",
+                "tile_long_rows", "tile_long_items", "tile_long_entries", "tile_split_rows", "stream_bytes"):
+        assert ih[key] == idv[key], (what, key, ih[key], idv[key])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tile_plan_built_on_the_device_is_the_host_plan(gpu, oracle, dtype):
+    """the csr_tile plan built by kernels from the CSR arrays in HBM (tile_plan_device.hpp: keys,
+    segmented sort, greedy cuts per row block, per-pass re-sort, remainder) is BYTE FOR BYTE the plan tile_plan.hpp
+    builds on host threads -- every array of both plans (ordinary tiles and the long rows' own), on scattered columns
+    (gather passes), a band (packed plan), a band with stray entries (packed plan + remainder), skewed rows (long-row
+    plan, split rows), empty rows and empty blocks, blocks of a single pass; and the device-built plan runs right."""
+    rng = np.random.default_rng(71)
+    cases = []
+    M, N = 9001, 2_000_003
+    rp, col, val = scattered(rng, M, N, 18, dtype=dtype)
+    cases.append(("uniform", M, N, rp, col, val, dict(stream_tile=1, tile_rows=1024, stream_local=0)))
+    M = N = 60_000
+    rp, col, val = scattered(rng, M, N, 9, sigma=2500, dtype=dtype)
+    cases.append(("band", M, N, rp, col, val, dict(stream_tile=1, tile_rows=2048, stream_local=0)))
+    stray = rng.random(rp[-1]) < 0.004
+    col2 = col.copy()
+    col2[stray] = rng.integers(0, N, int(stray.sum()))
+    rows = np.repeat(np.arange(M), np.diff(rp))
+    order = np.lexsort((col2, rows))
+    cases.append(("band + stray entries", M, N, rp, col2[order], val[order], dict(stream_tile=1, tile_rows=2048, stream_local=0)))
+    M, N = 6500, 3_000_000
+    lens = np.minimum((1.08 / rng.random(M)).astype(np.int64), 60000)
+    lens[rng.random(M) < 0.1] = 0
+    lens[1000:1700] = 0                      # a whole row block without entries
+    lens[[11, 3000, 6499]] = [50000, 5000, 900]
+    rp, col, val = scattered(rng, M, N, 0, dtype=dtype, lens=lens)
+    cases.append(("skewed, long-row plan", M, N, rp, col, val, dict(stream_tile=1, tile_rows=512, tile_lmax=700, tile_long=2)))
+    cases.append(("skewed, split rows", M, N, rp, col, val, dict(stream_tile=1, tile_rows=512, tile_lmax=700, tile_long=0)))
+    cases.append(("skewed, auto block height", M, N, rp, col, val, dict(stream_tile=1, tile_lmax=40, tile_long=2, tile_places=64)))
+    M, N = 3000, 50_000
+    rp, col, val = scattered(rng, M, N, 3, sigma=300, dtype=dtype)   # blocks that hold a single pass in CSR order
+    cases.append(("short rows, one pass per block", M, N, rp, col, val, dict(stream_tile=1, tile_rows=256, stream_local=0)))
+    for what, M, N, rp, col, val, knobs in cases:
+        with tuned(**knobs):
+            host, device = digests_by_builder(lambda: sp.CsrDevice(M, N, rp, col, val))
+            assert host[1]["stream_kernel"] == 3, what
+            assert_same_plan(host, device, what)
+            x = rng.uniform(-1, 1, N).astype(dtype)
+            with tuned(tile_plan_on_device=1):
+                with sp.CsrDevice(M, N, rp, col, val) as dev:
+                    check(dev, x, reference(oracle, rp, col, val, x, dtype), rp, col, val, dtype, what + " (device-built plan)")
+
+
+def test_hll_tile_plan_built_on_the_device_is_the_host_plan(gpu, oracle):
+    """The same for the tile plan over an HLL slab's rows (padding slots included): host-uploaded slab and the slab
+    built on the device from a resident CSR matrix."""
+    from _util import coo_from_csr
+    rng = np.random.default_rng(29)
+    M, N = 9001, 1_500_000
+    rp, col, val = scattered(rng, M, N, 16)
+    r, c, v = coo_from_csr(rp, col, val)
+    hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, N, r, c, v))
+    with tuned(stream_tile=1, tile_rows=1024, stream_local=0):
+        host, device = digests_by_builder(lambda: sp.HllDevice(hll))
+        assert host[1]["stream_kernel"] == 2
+        assert_same_plan(host, device, "hll slab")
+        with sp.CsrDevice(M, N, rp, col, val) as cdev:
+            built = digests_by_builder(lambda: sp.HllDevice.from_csr_device(cdev))
+        assert built[1][1]["stream_kernel"] == 2
+        assert_same_plan(host, built[1], "hll slab built on the device")
 
 
 def test_tile_kernel_row_block_handle_and_foreign_x(gpu, oracle):

@@ -50,3 +50,35 @@ for name, (M, row_ptr, col, val) in (("nlpkkt-like", synth.kkt_like(synth.KKT_GR
             d.close()
         print(f"{name:12s} COO ({label}) -> device CSR: host convert_in_csr {t1 - t:.3f} s + upload {t2 - t1:.3f} s; "
               f"spmv_hip_csr_from_coo {best:.3f} s", flush=True)
+
+
+# csr_tile plans: built on host threads (tile_plan.hpp) against built on the device (tile_plan_device.hpp, round 3)
+import scipy.sparse as sps
+
+
+def road_like(n=12_000_000, per_row=3, sigma=2000.0):
+    r = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    c = np.clip(r + np.rint(rng.normal(0, sigma, len(r))).astype(np.int64), 0, n - 1)
+    a = sps.csr_matrix((rng.uniform(-1, 1, len(r)), (r, c)), shape=(n, n))
+    a.sum_duplicates()
+    a.sort_indices()
+    return n, a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+
+
+for name, make in (("power-law 2^24 fp32", lambda: synth.powerlaw()), ("road-like 12 M rows fp64", road_like)):
+    n, rp_, col_, val_ = make()
+    set_tuning("place_tries", 0)
+    for on_device in (0, 1, 1):
+        set_tuning("tile_plan_on_device", on_device)
+        t = time.perf_counter()
+        d = sp.CsrDevice(n, n, rp_, col_, val_)
+        sp.hip_sync()
+        dt = time.perf_counter() - t
+        info = d.info()
+        print(f"{name:26s} upload incl. csr_tile plan, built on the {'device' if on_device else 'host  '}: {dt:.3f} s "
+              f"(blocks {info['tile_blocks']}, passes {info['tile_passes']}, long-row items {info['tile_long_items']}, "
+              f"digest {hash(tuple(d.tile_digest())) & 0xffffffff:08x})", flush=True)
+        d.close()
+    set_tuning("tile_plan_on_device", 1)
+    set_tuning("place_tries", 3)
+    del rp_, col_, val_
