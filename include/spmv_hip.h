@@ -100,6 +100,10 @@ typedef struct {
     long long tile_long_entries;   /* CSR: entries it holds */
     long long tile_staged_cols;    /* CSR: x values the staged passes copy to LDS per SpMV (all tile plans): traffic served by L2 */
     long long tile_remainder_entries; /* CSR: ... of tile_entries, in windows too sparse for a pass: added to y by tile_remainder behind the tiles */
+    int tile_mid_rows;             /* CSR: rows of the MIDDLE tier of a scattered plan (128 < entries <= tile_lmax, compacted into
+                                      blocks as tall as the LDS takes, packed plan, work items + slabs like the long rows) */
+    int tile_mid_items;            /* CSR: workgroups of that plan */
+    long long tile_mid_entries;    /* CSR: entries it holds */
     int place_tries;       /* placements of the value array that upload timed (0: not tuned -- small handle, or "place_tries" 0) */
     float place_first_us;  /* kernel time at the placement hipMalloc gave first */
     float place_best_us;   /* ... at the placement the handle kept */
@@ -159,6 +163,8 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
+ *                     "tile_mid" 1 | 0 a scattered plan gives its rows of more than 128 entries (up to tile_lmax) a tier of their
+ *                     own -- compacted, blocks as tall as the LDS takes, every pass staged -- when they hold >= 2^22 entries;
  *                     "tile_plan_on_device" 1 | 0 the plan is built by kernels from the CSR arrays in HBM (round 3) or by host
  *                     threads; the two builders give the same bytes;
  *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 32 KiB window and
@@ -169,7 +175,7 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     csr_stream) | 5 x-window | 6 csr_tile |
  *                     0 csr_stream; only in a `make EXPERIMENTAL=1` build: 1 row walk | 2 persistent pipe |
  *                     3 persistent row walk | 4 loader/consumer ring | 10..17 ablation probes (measurement only)
- *     "place_tries"   (3) read at upload: how many other placements of the value array a handle that streams >= 128 MiB of
+ *     "place_tries"   (8) read at upload: how many other placements of the value array a handle that streams >= 128 MiB of
  *                     values tries (a fresh allocation each, the kernel timed 2 + 6 launches on it), keeping the fastest.
  *                     Round 3 found the x-window kernel's time on the headline matrix to depend on WHERE the values lie:
  *                     the same matrix runs in 182-187 or in 199-205 us, deterministically per address
@@ -218,8 +224,8 @@ int spmv_hip_csr_tile_plan_check(int M, int N, const int *row_ptr, const int *co
  * block, work items of the long rows' plan, entries in the ordinary tiles. */
 int spmv_hip_csr_tile_auto_plan(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, long long *stats);
 /* Digests of the arrays of a handle's csr_tile plans (the tests' way of saying "the plan built on the device is the plan
- * the host builder makes"): digest[2 k] = elements, digest[2 k + 1] = a hash of the bytes of array k, 22 arrays (entry
- * arrays, pass descriptors, stream tables, remainder, the long rows' plan); digest has 44 entries. */
+ * the host builder makes"): digest[2 k] = elements, digest[2 k + 1] = a hash of the bytes of array k, 32 arrays (entry
+ * arrays, pass descriptors, stream tables, remainder, the long rows' plan, the middle tier); digest has 64 entries. */
 int spmv_hip_csr_tile_digest(const spmv_csr_dev *m, unsigned long long *digest);
 int spmv_hip_hll_tile_digest(const spmv_hll_dev *m, unsigned long long *digest);
 /* COO triplets (0-based, any order) -> a CSR handle, built ON THE DEVICE (upload of the

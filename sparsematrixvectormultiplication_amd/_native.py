@@ -55,6 +55,7 @@ class DevInfo(C.Structure):
                 ("tile_entries", C.c_longlong), ("tile_staged_entries", C.c_longlong),
                 ("tile_long_rows", C.c_int), ("tile_long_items", C.c_int), ("tile_long_entries", C.c_longlong),
                 ("tile_staged_cols", C.c_longlong), ("tile_remainder_entries", C.c_longlong),
+                ("tile_mid_rows", C.c_int), ("tile_mid_items", C.c_int), ("tile_mid_entries", C.c_longlong),
                 ("place_tries", C.c_int), ("place_first_us", C.c_float), ("place_best_us", C.c_float),
                 ("val_address", C.c_ulonglong)]
 

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
     T *prod = reinterpret_cast<T *>(hll_dyn_lds) + 16 / sizeof(T) * 2;  // [stage_slots + 2]
     const int t = threadIdx.x;
     const int4 d = desc[blockIdx.x];
-    const int row_first = d.x, nrows = d.y;
+    const int row_first = d.x, nrows = d.y & 0xffff;
+    const int window_slots = (int)((unsigned)d.y >> 16);  // slots from the even base to the window's end (0: one very long row)
     const long long first_slot = ((long long)d.w << 32) | (unsigned)d.z;
     const long long base = first_slot & ~1LL;  // 8/16-byte aligned stage loads
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
         lo = (int)(hack_off[h] + (long long)(r % kHack) * m - base);
     };
 
-    if (nrows == 1) {
+    if (nrows == 1 && (window_slots == 0 || window_slots > stage_slots)) {
         int lo1, m1;
         row_range(0, lo1, m1);
         if (lo1 + m1 > stage_slots) {
@@ -235,13 +236,19 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
     }
     const int rows_per_pass = kBlock / lanes;
     const int my_row = t / lanes, my_lane = t % lanes;
-    int lo = 0, m_row = 0;
-    if (my_row < nrows) row_range(my_row, lo, m_row);
-    // the window ends with its last row
-    int last_lo, last_m;
-    row_range(nrows - 1, last_lo, last_m);
-    stage_products<T, NT, MAXU>(prod, JA, AS, x, base, last_lo + last_m);
+    // the first pass's row extent: the RAW table values are loaded here, next to the stream, and turned into a slot range
+    // behind the stage (computing it on the spot makes the compiler wait for the tables before the stream has gone out:
+    // see hll_lds_local); how much to stage comes with the descriptor
+    int m0 = 0;
+    long long ho0 = 0;
+    if (my_row < nrows) {
+        const int h = (row_first + my_row) / kHack;
+        m0 = maxnz[h];
+        ho0 = hack_off[h];
+    }
+    stage_products<T, NT, MAXU>(prod, JA, AS, x, base, window_slots);
     __syncthreads();
+    int lo = my_row < nrows ? (int)(ho0 + (long long)((row_first + my_row) % kHack) * m0 - base) : 0, m_row = m0;
     for (int first = 0; first < nrows; first += rows_per_pass) {
         const int q = first + my_row;
         if (first > 0) {
@@ -292,8 +299,12 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
     const int lanes = lanes_for_rows<kBlock>(nrows);
     const int rows_per_pass = kBlock / lanes;
     const int my_row = t / lanes, my_lane = t % lanes;
-    int lo = 0, m_row = 0;
-    if (my_row < nrows) row_range(my_row, lo, m_row);  // consumed after the stage: rides along with it
+    // The first pass's row extent rides along with the stream: the RAW word is loaded here and decoded behind the stage.
+    // (Decoding it on the spot -- as this kernel did until round 3 -- makes the compiler wait for it, vmcnt(0), BEFORE
+    // the block's stream loads have gone out: one exposed memory latency per block, and the reason hll_lds_local ran
+    // 7 % behind csr_stream_local on identical data: profiles/r3_hll_as_csr_*.txt, r3_isa_mix_*.txt.)
+    unsigned seg0 = 0;
+    if (my_row < nrows) seg0 = row_seg[row_first + my_row];
     // the slot count comes with the descriptor, so the stream does not wait for the hack table
     const int count = ld.z;
     const int units = (count + kUnit - 1) / kUnit;                            // wave-uniform
@@ -336,6 +347,7 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
             if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = p[u];
     }
     __syncthreads();
+    int lo = (int)(seg0 & 0xffffu), m_row = (int)(seg0 >> 16);
     for (int first = 0; first < nrows; first += rows_per_pass) {
         const int q = first + my_row;
         if (first > 0) {

@@ -89,7 +89,8 @@ int g_tile_rows = 0;
 int g_tile_lmax = 1024;
 int g_tile_density = 4;
 int g_tile_plan_on_device = 1;
-int g_place_tries = 3;
+int g_place_tries = 8;
+int g_tile_mid = 1;
 int g_tile_probe = 0;
 int g_skew_rows = 1;
 int g_tile_fit = 1;
@@ -249,6 +250,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_skew_rows = value != 0;
     } else if (!strcmp(key, "tile_probe")) {
         g_tile_probe = value & 15;
+    } else if (!strcmp(key, "tile_mid")) {
+        g_tile_mid = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "place_tries")) {
         if (value < 0 || value > 16) return fail("set_tuning: place_tries must be 0..16");
         g_place_tries = value;  // takes effect at the next upload

@@ -63,6 +63,8 @@ extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keep
 extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile plan of their own (compacted rows, work items, slabs)
 extern int g_tile_pack;       // 1: passes that can be staged store head | row | column offset in one 32-bit word (no key read)
 extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
+constexpr int kTileMidLo = 128;  // a scattered matrix's rows longer than this (up to tile_lmax) form the middle tier
+extern int g_tile_mid;        // 1: scattered plans get that tier (when it holds >= 2^22 entries), 0: never
 extern int g_place_tries;     // other placements of the value array upload tries for large handles (0: none)
 extern int g_tile_plan_on_device;  // 1: the csr_tile plan is built by kernels (tile_plan_device.hpp), 0: by host threads (tile_plan.hpp)
 extern int g_num_cus;
@@ -226,7 +228,9 @@ struct spmv_csr_dev {
         int *tcol = nullptr;
         unsigned short *tkey = nullptr;
         void *tval = nullptr, *slab = nullptr;
-    } lt;
+    } lt, mt;  // lt: rows beyond tile_lmax (2048 compacted rows per block); mt (round 3): the MIDDLE tier of a scattered
+               // matrix, rows of kTileMidLo < entries <= tile_lmax in blocks as tall as the LDS takes, so that their
+               // column ranges hold enough entries to be staged as well
     int4 *tile_long_rows = nullptr;   // rows beyond the tile limit {row, first slot, pieces, 0} ...
     int4 *tile_pieces = nullptr;      // ... and their pieces, cut at column stripes, stripe by stripe
     int tile_num_long = 0, tile_num_pieces = 0;

@@ -65,11 +65,14 @@ struct CutParams {
 
 constexpr int kCutBlock = 256;
 
-// slice blockIdx.y of block blockIdx.x: one wavefront per row, lanes over the row's entries
+// slice blockIdx.y of block blockIdx.x: one wavefront per row, lanes over the row's entries.
+// PAIRS = false: keys[k] = column << 32 | local row << pos_bits | position (one segment per block for the segmented sort);
+// PAIRS = true:  keys[k] = block << 32 | column, payload[k] = local row << pos_bits | position (one global stable sort)
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void tile_fill_keys(int B, const int *__restrict__ block_row, const int *__restrict__ row_begin,
                                                       const int *__restrict__ row_len, const int *__restrict__ koff,
                                                       const int *__restrict__ col, int lmax, int pos_bits,
-                                                      unsigned long long *__restrict__ keys) {
+                                                      unsigned long long *__restrict__ keys, unsigned *__restrict__ payload) {
     const int b = blockIdx.x;
     if (b >= B) return;
     const int r0 = block_row[b], r1 = block_row[b + 1];
@@ -80,10 +83,24 @@ __global__ __launch_bounds__(256) void tile_fill_keys(int B, const int *__restri
         const int len = row_len[r];
         if (len > lmax) continue;
         const int beg = row_begin[r], o = koff[r];
-        const unsigned long long hi = (unsigned long long)(unsigned)(r - r0) << pos_bits;
-        for (int k = lane; k < len; k += 64)
-            keys[(size_t)o + k] = ((unsigned long long)(unsigned)col[(size_t)beg + k] << 32) | hi | (unsigned)k;
+        const unsigned hi = (unsigned)(r - r0) << pos_bits;
+        for (int k = lane; k < len; k += 64) {
+            const unsigned c = (unsigned)col[(size_t)beg + k];
+            if (PAIRS) {
+                keys[(size_t)o + k] = ((unsigned long long)(unsigned)b << 32) | c;
+                payload[(size_t)o + k] = hi | (unsigned)k;
+            } else {
+                keys[(size_t)o + k] = ((unsigned long long)c << 32) | hi | (unsigned)k;
+            }
+        }
     }
+}
+
+// (block << 32 | column, payload) -> column << 32 | payload: what the cut and emit kernels read
+__global__ __launch_bounds__(256) void tile_repack_keys(size_t n, const unsigned long long *__restrict__ bc,
+                                                        const unsigned *__restrict__ payload, unsigned long long *__restrict__ keys) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256)
+        keys[k] = (bc[k] << 32) | payload[k];
 }
 
 // sum of `v` over the workgroup, the same value in every thread (v is a per-wave count already)
@@ -352,12 +369,35 @@ int tile_build_device(int M, int N, const TileDevInput<T> &in, const int *h_row_
     trace.mark("row blocks, offsets, allocation");
     // 1. keys, block after block (few blocks: more slices each, so that the chip still has work)
     const int slices = B >= 2048 ? 1 : B >= 256 ? 8 : 64;
-    hipLaunchKernelGGL(tile_fill_keys, dim3(B, slices), dim3(256), 0, s, B, d_block_row, in.row_begin, in.row_len, d_koff, in.col,
-                       lmax, pos_bits, d_keys_a);
-    trace.mark("keys");
-    // 2. one segment per row block; only the bits that can differ
+    // 2. sort.  Many blocks of moderate size: one segment per row block.  A FEW HUGE blocks (the long rows' plan: ten
+    // blocks of 1.5e7 keys) are the segmented sort's worst case -- 0.49 s for 1.4e8 keys where the ordinary plan's
+    // 1.2e8 keys in 1260 segments take 9 ms: those go through ONE stable radix sort of (block << 32 | column) with the
+    // (local row, position) word as payload -- CSR order among equal (block, column), the same total order.
     unsigned long long *sorted = d_keys_a;
-    if (n_total > 0) {
+    const bool few_huge = n_total / (size_t)B >= ((size_t)1 << 20);
+    if (few_huge) {
+        unsigned *d_pay_a = nullptr, *d_pay_b = nullptr;
+        e = tmp.alloc(&d_pay_a, n_total);
+        if (e == hipSuccess) e = tmp.alloc(&d_pay_b, n_total);
+        if (bad(e, "allocation")) return -1;
+        hipLaunchKernelGGL((tile_fill_keys<true>), dim3(B, slices), dim3(256), 0, s, B, d_block_row, in.row_begin, in.row_len, d_koff,
+                           in.col, lmax, pos_bits, d_keys_a, d_pay_a);
+        trace.mark("keys");
+        const unsigned end_bit = 32 + bits_for((unsigned long long)B);
+        size_t tmp_bytes = 0;
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_a, d_keys_b, d_pay_a, d_pay_b, n_total, 0u, end_bit, s);
+        void *d_tmp = nullptr;
+        if (e == hipSuccess) e = tmp.alloc((char **)&d_tmp, tmp_bytes);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys_a, d_keys_b, d_pay_a, d_pay_b, n_total, 0u, end_bit, s);
+        if (bad(e, "radix sort")) return -1;
+        hipLaunchKernelGGL(tile_repack_keys, dim3(4096), dim3(256), 0, s, n_total, d_keys_b, d_pay_b, d_keys_a);
+        sorted = d_keys_a;
+    } else {
+        hipLaunchKernelGGL((tile_fill_keys<false>), dim3(B, slices), dim3(256), 0, s, B, d_block_row, in.row_begin, in.row_len, d_koff,
+                           in.col, lmax, pos_bits, d_keys_a, (unsigned *)nullptr);
+        trace.mark("keys");
+    }
+    if (!few_huge && n_total > 0) {
         const unsigned end_bit = 32 + bits_for((unsigned long long)std::max(N, 1));
         size_t tmp_bytes = 0;
         e = rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, d_keys_a, d_keys_b, (unsigned)n_total, (unsigned)B, d_kb, d_kb + 1,

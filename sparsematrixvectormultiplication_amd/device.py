@@ -229,10 +229,10 @@ class CsrDevice(_Handle):
     ARRAYS = ("row_ptr", "col", "val", "x", "y", "lcol", "lines", "ldesc4")
 
     def tile_digest(self):
-        """(elements, hash) of each of the 22 arrays of the handle's tile plans (spmv_hip_csr_tile_digest)."""
-        out = (C.c_ulonglong * 44)()
+        """(elements, hash) of each of the 32 arrays of the handle's tile plans (spmv_hip_csr_tile_digest)."""
+        out = (C.c_ulonglong * 64)()
         _check(nat.lib().spmv_hip_csr_tile_digest(self.h, out), "spmv_hip_csr_tile_digest")
-        return [(int(out[2 * k]), int(out[2 * k + 1])) for k in range(22)]
+        return [(int(out[2 * k]), int(out[2 * k + 1])) for k in range(32)]
 
     def stamp_blocks(self, warm: int = 3):
         """(start, end, dispatch id, xcd) per x-window block of one stamped launch; times in ticks of 10 ns."""
@@ -395,9 +395,9 @@ class HllDevice(_Handle):
     y_ptr = property(lambda s: nat.lib().spmv_hip_hll_y_ptr(s.h) or 0)
 
     def tile_digest(self):
-        out = (C.c_ulonglong * 44)()
+        out = (C.c_ulonglong * 64)()
         _check(nat.lib().spmv_hip_hll_tile_digest(self.h, out), "spmv_hip_hll_tile_digest")
-        return [(int(out[2 * k]), int(out[2 * k + 1])) for k in range(22)]
+        return [(int(out[2 * k]), int(out[2 * k + 1])) for k in range(32)]
 
     def download(self):
         """(hack_off, maxnz, JA, AS) of the flat device slab."""

@@ -38,7 +38,7 @@ class tuned:
     def __exit__(self, *exc):
         defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 4, "stream_kind": -1,
                     "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1, "tile_places": 0,
-                    "tile_streams": 1, "tile_fit": 1, "tile_plan_on_device": 1, "place_tries": 3, "tile_min_pass": 256}
+                    "tile_streams": 1, "tile_fit": 1, "tile_plan_on_device": 1, "place_tries": 8, "tile_min_pass": 256, "tile_mid": 1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 
@@ -184,7 +184,8 @@ def test_tile_kernel_skewed_rows_sub_runs_and_split_rows(gpu, oracle, dtype):
 
 DIGEST_ARRAYS = ("tcol", "tkey", "tval", "pass", "stream_pass", "block_row", "stream_block", "sblock_rows", "rem_row", "rem_ptr",
                  "rem_col", "rem_val", "lt.tcol", "lt.tkey", "lt.tval", "lt.pass", "lt.block_row", "lt.block_pass", "lt.work",
-                 "lt.item_first", "lt.row_map", "lt.block_of_row")
+                 "lt.item_first", "lt.row_map", "lt.block_of_row", "mt.tcol", "mt.tkey", "mt.tval", "mt.pass", "mt.block_row",
+                 "mt.block_pass", "mt.work", "mt.item_first", "mt.row_map", "mt.block_of_row")
 
 
 def digests_by_builder(make_handle):
@@ -202,7 +203,8 @@ def assert_same_plan(host, device, what):
     for name, a, b in zip(DIGEST_ARRAYS, dh, dd):
         assert a == b, f"{what}: array {name} differs between the host-built and the device-built plan: {a} vs {b}"
     for key in ("tile_blocks", "tile_passes", "tile_entries", "tile_staged_entries", "tile_staged_cols", "tile_remainder_entries",
-                "tile_long_rows", "tile_long_items", "tile_long_entries", "tile_split_rows", "stream_bytes"):
+                "tile_long_rows", "tile_long_items", "tile_long_entries", "tile_mid_rows", "tile_mid_items", "tile_mid_entries",
+                "tile_split_rows", "stream_bytes"):
         assert ih[key] == idv[key], (what, key, ih[key], idv[key])
 
 

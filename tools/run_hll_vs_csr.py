@@ -19,6 +19,10 @@ with sp.CsrDevice(M, M, rp, col, val) as dev:
     dev.set_x(np.ones(M))
     with sp.HllDevice.from_csr_device(dev) as h:
         h.set_x(np.ones(M))
+        # (round 3: where the value array lies moves either kernel by up to 8 % -- what upload's placement tuning saw)
+        for name, info in (("csr", dev.info()), ("hll", h.info())):
+            print(f"{name}: {info['place_tries']} placements timed at upload, first {info['place_first_us']:.1f} us, kept "
+                  f"{info['place_best_us']:.1f} us, values at {info['val_address']:#x}", flush=True)
         for r in range(rounds):
             hms = h.time(sp.HLL_LDS, 2, 20, zero_y=False)
             ms = dev.time(sp.CSR_STREAM, 2, 20, zero_y=False)
