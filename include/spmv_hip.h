@@ -163,6 +163,9 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
+ *                     "tile_gather_ahead" 0 | 1 (read at launch) plans with gather passes send a pass's gathers out one pass
+ *                     early (twice as many in flight per CU) -- measured to buy nothing (1113 vs 1108 us on config 5, 514.9 vs
+ *                     514.8 on uniformly random columns: profiles/r3_ab_gather_ahead.txt), hence off;
  *                     "tile_mid" 1 | 0 a scattered plan gives its rows of more than 128 entries (up to tile_lmax) a tier of their
  *                     own -- compacted, blocks as tall as the LDS takes, every pass staged -- when they hold >= 2^22 entries;
  *                     "tile_plan_on_device" 1 | 0 the plan is built by kernels from the CSR arrays in HBM (round 3) or by host

@@ -335,7 +335,8 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
                     else dev_ok = false;
                 }
                 return build_at(rows, begin_h, len_h, d_begin, d_len, rpb, lmax, pos_bits, pack, 0, 0, plan, tb.ltiles_dev);
-            });
+            },
+            want_mid ? g_tile_lmax : 0);  // (with a middle tier the long rows' plan starts behind it)
     // the middle tier: what the ordinary tiles left out up to tile_lmax (the long rows' plan has taken the rest)
     if (want_mid && tb.have_tiles)
         tb.have_mid_tiles = build_long_tiles<T>(
@@ -384,8 +385,10 @@ int tile_allow_lds() {
     static int done_for_device = -1;
     const bool done = done_for_device == g_device;
     if (done) return 0;
-    const void *fns[4] = {(const void *)csr_tile<T, false, 2048, kTileTrips, false>, (const void *)csr_tile<T, true, 2048, kTileTrips, false>,
-                          (const void *)csr_tile<T, false, 2048, kTileTrips, true>, (const void *)csr_tile<T, true, 2048, kTileTrips, true>};
+    const void *fns[6] = {(const void *)csr_tile<T, false, 2048, kTileTrips, false>, (const void *)csr_tile<T, true, 2048, kTileTrips, false>,
+                          (const void *)csr_tile<T, false, 2048, kTileTrips, true>, (const void *)csr_tile<T, true, 2048, kTileTrips, true>,
+                          (const void *)csr_tile<T, false, 2048, kTileTrips, false, true>,
+                          (const void *)csr_tile<T, true, 2048, kTileTrips, false, true>};
     for (const void *fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for_device = g_device;
     return 0;
@@ -1838,8 +1841,15 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                        m->tile_streams, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,       \
                        m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval,        \
                        m->tile_stream_block, m->tile_sblock_rows, x, y)
+#define SPMV_TILE_GA(NT)                                                                                               \
+    hipLaunchKernelGGL((csr_tile<T, NT, 2048, kTileTrips, false, true>), dim3((m->tile_streams + 7) / 8 * 8), dim3(kTileBlock), lds, s, \
+                       m->tile_streams, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,       \
+                       m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval,        \
+                       m->tile_stream_block, m->tile_sblock_rows, x, y)
                     if (m->tile_packed) { if (which) SPMV_TILE(true, true); else SPMV_TILE(false, true); }
+                    else if (g_tile_gather_ahead) { if (which) SPMV_TILE_GA(true); else SPMV_TILE_GA(false); }  // gathers one pass early
                     else { if (which) SPMV_TILE(true, false); else SPMV_TILE(false, false); }
+#undef SPMV_TILE_GA
 #undef SPMV_TILE
                     if (m->tile_rem_rows > 0)  // what the packed plan left out: added behind the tiles
                         hipLaunchKernelGGL((tile_remainder<T>), dim3((m->tile_rem_rows + 255) / 256), dim3(256), 0, s, m->tile_rem_rows,

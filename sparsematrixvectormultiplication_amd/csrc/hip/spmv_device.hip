@@ -91,6 +91,7 @@ int g_tile_density = 4;
 int g_tile_plan_on_device = 1;
 int g_place_tries = 8;
 int g_tile_mid = 1;
+int g_tile_gather_ahead = 0;  // measured: no gain (profiles/r3_ab_gather_ahead.txt)
 int g_tile_probe = 0;
 int g_skew_rows = 1;
 int g_tile_fit = 1;
@@ -250,6 +251,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_skew_rows = value != 0;
     } else if (!strcmp(key, "tile_probe")) {
         g_tile_probe = value & 15;
+    } else if (!strcmp(key, "tile_gather_ahead")) {
+        g_tile_gather_ahead = value != 0;  // read at launch
     } else if (!strcmp(key, "tile_mid")) {
         g_tile_mid = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "place_tries")) {

@@ -64,6 +64,7 @@ extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile pl
 extern int g_tile_pack;       // 1: passes that can be staged store head | row | column offset in one 32-bit word (no key read)
 extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
 constexpr int kTileMidLo = 128;  // a scattered matrix's rows longer than this (up to tile_lmax) form the middle tier
+extern int g_tile_gather_ahead;  // 1: plans with gather passes run the csr_tile instantiation that gathers one pass early
 extern int g_tile_mid;        // 1: scattered plans get that tier (when it holds >= 2^22 entries), 0: never
 extern int g_place_tries;     // other placements of the value array upload tries for large handles (0: none)
 extern int g_tile_plan_on_device;  // 1: the csr_tile plan is built by kernels (tile_plan_device.hpp), 0: by host threads (tile_plan.hpp)

@@ -190,7 +190,30 @@ __device__ __forceinline__ void chain_scan(T &r, int &h, int lane) {
 // before that slice, so what stays in flight across the wait is what was sent out after it -- with the slice one
 // pass ahead that was ONE pass's entries per workgroup (24 KB; 4.1-4.4 TB/s for the bare stream of entries), with
 // it two passes ahead it is two.  Past the block's last pass the loads repeat that pass.
-template <typename T, bool NT, int CH, int TRIPS, bool PACK>
+// GA (gather ahead, round 3; plans with gather passes only; OFF by default: it did not pay, see the end of this comment): the gathers of a pass go out one pass EARLY -- at the top
+// of the pass before it, from that pass's column words (nc, in registers since two passes), into the other of two
+// register sets (xn) -- and this pass works on the set filled a pass ago (xg).  Without it a pass's gathers are sent
+// and awaited inside the pass: 8 wavefronts x 4 values = 32 gather wave-instructions in flight per CU, against the 128
+// the gather probe needs for its 265 G values / s; config 5's short rows ran at 128 G values / s.  All of them go
+// out unconditionally (a staged pass gathers its window's first column, one line for everybody): the number of loads
+// in flight stays a compile-time constant, which is what lets vmcnt leave the later ones in flight.
+// Measured (profiles/r3_ab_gather_ahead.txt): the waits come out as designed (vmcnt up to 21 in the fp32 kernel) and the
+// time does not move -- config 5 1113 -> 1108 us, uniformly random columns 514.9 -> 514.8: the gathers in flight per
+// wavefront are not what bounds these passes.  Kept behind "tile_gather_ahead" for the record.
+template <typename T, int Q>
+__device__ __forceinline__ void tile_issue_gathers(T (&xn)[4 * Q], const v4i (&nc)[Q], const int4 dn, int stage_ok,
+                                                   const T *__restrict__ x) {
+    const int t = threadIdx.x;
+    const bool gathers = !(stage_ok && (dn.w & kTileWlenMask));
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+        const int i = u * 4 * kTileBlock + 4 * t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xn[4 * u + q] = gather(x, gathers && i + q < dn.y ? nc[u][q] : dn.z);
+    }
+}
+
+template <typename T, bool NT, int CH, int TRIPS, bool PACK, bool GA = false>
 __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u (&ck)[CH / (4 * kTileBlock)],
                                           typename vec4v<T>::type (&cv)[CH / (4 * kTileBlock)], v4u (&cw)[TRIPS],
                                           v4i (&fc)[CH / (4 * kTileBlock)], v2u (&fk)[CH / (4 * kTileBlock)],
@@ -199,7 +222,9 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
                                           int probe, int &bi, const int2 *__restrict__ sblock_rows, int rows_per_block,
                                           T *__restrict__ y, T *acc, T *xs, T *wave_r, int *wave_h,
                                           const int *__restrict__ tcol, const unsigned short *__restrict__ tkey,
-                                          const T *__restrict__ tval, const T *__restrict__ x) {
+                                          const T *__restrict__ tval, const T *__restrict__ x,
+                                          const v4i (&nc)[CH / (4 * kTileBlock)], const int4 dn,
+                                          T (&xg)[GA ? CH / kTileBlock : 1], T (&xn)[GA ? CH / kTileBlock : 1]) {
     constexpr int kQuads = CH / (4 * kTileBlock);
     constexpr int kPer = 16 / (int)sizeof(T);
     // (the probe bits stay run-time tests on purpose: with them folded to constants this compiler's register
@@ -228,8 +253,10 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
             if (k * kTileBlock * kPer < wlen) *reinterpret_cast<v4u *>(xs + j) = cw[k];
         }
     }
-    T xv[PACK ? 1 : 4 * kQuads];
-    if constexpr (!PACK) {
+    T xv[(PACK || GA) ? 1 : 4 * kQuads];
+    if constexpr (GA) {
+        tile_issue_gathers<T, kQuads>(xn, nc, dn, stage_ok, x);  // the NEXT pass's values; this pass's are in xg
+    } else if constexpr (!PACK) {
         if (!wlen && !(probe & 2)) {  // gathers go out first (vmcnt retires in order): they are back when the barrier opens
 #pragma unroll
             for (int u = 0; u < kQuads; ++u) {
@@ -272,6 +299,7 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
             } else {
                 key = (q & 1 ? ck[u][q >> 1] >> 16 : ck[u][q >> 1]) & 0xffffu;
                 if (wlen) xq = xs[in ? (int)word - wbase : 0];
+                else if constexpr (GA) xq = xg[4 * u + q];
                 else xq = (probe & 2) ? T(1) : xv[4 * u + q];
             }
             const T pr = in ? cv[u][q] * xq : T(0);
@@ -353,7 +381,7 @@ __device__ __forceinline__ void tile_pass(v4i (&cc)[CH / (4 * kTileBlock)], v2u 
 // passes p + 1, p + 2 and the entries of passes p + 1 .. p + 3 are already on their way into registers.
 // pass = {first entry (multiple of 4), entries, first staged column (multiple of 4), staged columns (0: gather)}
 // (second launch bound = wavefronts per SIMD: two resident workgroups per CU)
-template <typename T, bool NT, int CH, int TRIPS, bool PACK>
+template <typename T, bool NT, int CH, int TRIPS, bool PACK, bool GA = false>
 __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int rows_per_block,
                                                                           int stage_ok, int probe,
                                                                           const int4 *__restrict__ work, T *__restrict__ slab,
@@ -409,10 +437,13 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
         SPMV_TILE_ENTRY_REGS(e1);
         v4u wa[TRIPS], wb[TRIPS];
         const int pl = p1 - 1;
-#define SPMV_TILE_PASS(cur, fill, wcur, D, DW, DE, P)                                                             \
-    tile_pass<T, NT, CH, TRIPS, PACK>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), D, DW, DE, (P) <= pl, \
-                                      stage_ok, probe, bi, flush_rows, rows_per_block, y, acc, xs, wave_r, wave_h, tcol, tkey,   \
-                                      tval, x)
+        // (GA: two sets of gathered values, this pass's and the next one's; one dummy element otherwise)
+        T xa[GA ? CH / kTileBlock : 1], xb[GA ? CH / kTileBlock : 1];
+#define SPMV_TILE_PASS(cur, fill, wcur, D, DW, DE, P) SPMV_TILE_PASS_GA(cur, fill, wcur, D, DW, DE, P, cur, D, xa, xa)
+#define SPMV_TILE_PASS_GA(cur, fill, wcur, D, DW, DE, P, nxt, DN, XG, XN)                                            \
+    tile_pass<T, NT, CH, TRIPS, PACK, GA>(SPMV_TILE_ENTRY_ARGS(cur), wcur, SPMV_TILE_ENTRY_ARGS(fill), D, DW, DE, (P) <= pl, \
+                                          stage_ok, probe, bi, flush_rows, rows_per_block, y, acc, xs, wave_r, wave_h, tcol, tkey, \
+                                          tval, x, nxt##_c, DN, XG, XN)
         SPMV_TILE_ENTRY_REGS(e2);
         SPMV_TILE_ENTRY_REGS(e3);
         // descriptors of passes p .. p + 3 (clamped to the block's last pass), replaced one per pass
@@ -455,6 +486,24 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
                     if (p + 2 < p1) SPMV_TILE_PASS(e2, e1, wa, d2, d3, d3, p + 2);
                 }
             }
+        } else if constexpr (GA) {
+            // gather ahead: pass p works on the values gathered during pass p - 1 and sends out those of pass p + 1
+            // (the prologue sends out pass p0's: its entries are the oldest loads in the queue)
+            tile_issue_gathers<T, kQuads>(xa, e0_c, d0, stage_ok, x);
+            for (int p = p0; p < p1; p += 4) {  // wave-uniform
+                const int4 n0 = pass_desc[min(p + 4, pl)];
+                SPMV_TILE_PASS_GA(e0, e3, wa, d0, d2, d3, p, e1, d1, xa, xb);
+                const int4 n1 = pass_desc[min(p + 5, pl)];
+                if (p + 1 < p1) SPMV_TILE_PASS_GA(e1, e0, wb, d1, d3, n0, p + 1, e2, d2, xb, xa);
+                const int4 n2 = pass_desc[min(p + 6, pl)];
+                if (p + 2 < p1) SPMV_TILE_PASS_GA(e2, e1, wa, d2, n0, n1, p + 2, e3, d3, xa, xb);
+                const int4 n3 = pass_desc[min(p + 7, pl)];
+                if (p + 3 < p1) SPMV_TILE_PASS_GA(e3, e2, wb, d3, n1, n2, p + 3, e0, n0, xb, xa);
+                d0 = n0;
+                d1 = n1;
+                d2 = n2;
+                d3 = n3;
+            }
         } else {
             // (plans with gather passes wait for their gathers in every pass anyway -- which drains the queue down to
             // what went out behind them -- and with the tail passes written out these instantiations spill)
@@ -474,6 +523,7 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
             }
         }
 #undef SPMV_TILE_PASS
+#undef SPMV_TILE_PASS_GA
     }
     if (out) {  // (a stream has written its rows block by block)
         __syncthreads();

@@ -118,7 +118,9 @@ def test_c5_powerlaw_fp32_full_size_properties(gpu, oracle):
     with sp.CsrDevice(n, n, row_ptr, col, val) as dev:
         info = dev.info()
         assert info["stream_kernel"] == 3 and info["tile_entries"] < info["nz"]       # csr_tile ...
-        assert info["tile_entries"] + info["tile_long_entries"] == info["nz"]          # ... + the long rows' tiles
+        # ... + the long rows' tiles + (round 3) the middle tier: rows of 128 < entries <= 1024 in LDS-tall blocks
+        assert info["tile_entries"] + info["tile_long_entries"] + info["tile_mid_entries"] == info["nz"]
+        assert info["tile_mid_entries"] > 3e7 and info["tile_mid_rows"] > 1e5 and info["tile_mid_items"] > 0
         assert info["tile_long_rows"] > 1000 and info["tile_split_rows"] == 0
         y1 = dev.spmv(x1, sp.CSR_AUTO)
         sample_check(y1, x1, "powerlaw full size")
