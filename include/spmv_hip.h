@@ -151,8 +151,8 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *     "skew_rows"     1 | 0   handles that run the gather kernels give rows longer than max(128, 16 x the average
  *                     row) to the split-row kernels (one workgroup per row piece) instead of leaving each to one lane
  *     "stream_tile"   -1 (auto) | 0 | 1   build the 2-D tile plan (csr_tile) when the matrix gets no x-window plan;
- *                     "tile_rows" 0 (auto: 32 KiB of accumulators for banded matrices, up to 16384 rows for scattered
- *                     ones) | a multiple of 256 in 256..16384 rows per block; "tile_lmax" (1024) longest row kept in
+ *                     "tile_rows" 0 (auto: 32 KiB of accumulators for banded matrices, as many rows as the LDS takes for
+ *                     scattered ones: 16128 fp64 / 32512 fp32) | a multiple of 256 in 256..32768 rows per block; "tile_lmax" (1024) longest row kept in
  *                     the ordinary tiles; "tile_density" (4) columns per entry up to which a pass is staged in LDS;
  *                     "tile_balance" 1 | 0 row blocks of equal entry / row counts; "tile_long" 1 | 0 | 2 a tile plan of
  *                     their own for the rows beyond tile_lmax (0: split-row kernels, 2: however few they are);
@@ -178,7 +178,7 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     csr_stream) | 5 x-window | 6 csr_tile |
  *                     0 csr_stream; only in a `make EXPERIMENTAL=1` build: 1 row walk | 2 persistent pipe |
  *                     3 persistent row walk | 4 loader/consumer ring | 10..17 ablation probes (measurement only)
- *     "place_tries"   (8) read at upload: how many other placements of the value array a handle that streams >= 128 MiB of
+ *     "place_tries"   (12) read at upload: how many other placements of the value array a handle that streams >= 128 MiB of
  *                     values tries (a fresh allocation each, the kernel timed 2 + 6 launches on it), keeping the fastest.
  *                     Round 3 found the x-window kernel's time on the headline matrix to depend on WHERE the values lie:
  *                     the same matrix runs in 182-187 or in 199-205 us, deterministically per address
@@ -212,7 +212,7 @@ int spmv_hip_csr_upload_f32(int M, int N, const int *row_ptr, const int *col_idx
  * rows, rows handed to the split-row kernels because they alone touch too many lines. */
 int spmv_hip_csr_plan_check(int M, int N, const int *row_ptr, const int *col_idx, int value_bytes, int *stats);
 /* The same for the csr_tile plan (row blocks x column passes, see spmv_dev_info.tile_*): builds it as upload
- * would with the given parameters (rows per block: multiple of 256 in 256..16384; lmax: longest row kept in the
+ * would with the given parameters (rows per block: multiple of 256 in 256..32768; lmax: longest row kept in the
  * tiles; density: columns per entry up to which a pass is staged; chunk: 2048 entries per pass; balance: 1 = row blocks of about equal entry counts) and replays the kernel's bookkeeping with
  * integer checksums; needs no device.  Both kinds of plan are built and checked: the one with gather passes, then
  * the PACKED one (every pass cut at the window and staged, column words carry the keys: what upload builds for

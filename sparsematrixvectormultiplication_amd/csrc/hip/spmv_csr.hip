@@ -689,7 +689,7 @@ int csr_plan_on_device(spmv_csr_dev *m, const std::vector<int4> &desc, long long
     return result;
 }
 
-// Where the value array lies decides -- deterministically per address, by a mechanism the counters at hand do not
+// Where the value array lies decides -- for as long as the allocation lives, by a mechanism the counters at hand do not
 // name (profiles/r3_placement_*.txt: not the XCD mapping, not the TLB, not one slow XCD; every block of one HALF of
 // the matrix is a little slower) -- whether the x-window kernel runs the headline matrix in 182-187 or in 199-205 us.
 // So a handle that streams enough values for it to matter times its own kernel on a few placements and keeps the best:

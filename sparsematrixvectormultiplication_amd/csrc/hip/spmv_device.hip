@@ -18,7 +18,9 @@ __global__ __launch_bounds__(kBlock) void flush_kernel(uint4 *__restrict__ buf, 
     }
 }
 
-// Read-only stream: every lane sums 16-byte non-temporal loads, one value per workgroup leaves the chip.
+// Read-only stream: every lane sums 16-byte non-temporal loads, one value per workgroup leaves the chip.  DEPTH loads in
+// flight per lane (4: the probe of rounds 2-3, which the issue side bounds at ~5.7 TB/s; 16: enough to lean on HBM itself).
+template <int DEPTH>
 __global__ __launch_bounds__(kBlock) void stream_probe_kernel(const uint4 *__restrict__ buf, size_t n,
                                                               unsigned *__restrict__ sink) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -26,10 +28,12 @@ __global__ __launch_bounds__(kBlock) void stream_probe_kernel(const uint4 *__res
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * kBlock;
     unsigned acc = 0;
-    for (; i + 3 * stride < n; i += 4 * stride) {  // four loads in flight per lane
-        const v4u a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
-        const v4u c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
-        acc += a.x ^ b.y ^ c.z ^ d.w;
+    for (; i + (DEPTH - 1) * stride < n; i += DEPTH * stride) {
+        v4u v[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) v[k] = __builtin_nontemporal_load(p + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) acc += v[k][k & 3];
     }
     for (; i < n; i += stride) acc += __builtin_nontemporal_load(p + i).x;
     if (acc == 0x9e3779b9u) sink[blockIdx.x] = acc;  // never true on the zeroed buffer: keeps the loads alive
@@ -89,7 +93,7 @@ int g_tile_rows = 0;
 int g_tile_lmax = 1024;
 int g_tile_density = 4;
 int g_tile_plan_on_device = 1;
-int g_place_tries = 8;
+int g_place_tries = 12;
 int g_tile_mid = 1;
 int g_tile_gather_ahead = 0;  // measured: no gain (profiles/r3_ab_gather_ahead.txt)
 int g_tile_probe = 0;
@@ -106,6 +110,7 @@ int g_tile_balance = 1;
 int g_pipe_wgs_per_cu = 5;
 int g_num_cus = 256;
 int g_probe_mask = 1023;
+static int g_probe_depth = 4;  // "probe_depth" tuning knob: loads in flight per lane of the stream probe (4 | 16)
 
 int fail(const char *fmt, ...) {
     va_list ap;
@@ -251,6 +256,9 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_skew_rows = value != 0;
     } else if (!strcmp(key, "tile_probe")) {
         g_tile_probe = value & 15;
+    } else if (!strcmp(key, "probe_depth")) {
+        if (value != 4 && value != 16) return fail("set_tuning: probe_depth must be 4 or 16");
+        g_probe_depth = value;
     } else if (!strcmp(key, "tile_gather_ahead")) {
         g_tile_gather_ahead = value != 0;  // read at launch
     } else if (!strcmp(key, "tile_mid")) {
@@ -352,8 +360,12 @@ static int stream_probe_run(const void *buf, size_t bytes, int warmup, int iters
     std::vector<float> ms((size_t)iters, 0.f);
     const int rc = time_loop(warmup, iters, ms.data(),
                              [&]() {
-                                 hipLaunchKernelGGL(stream_probe_kernel, dim3(grid), dim3(kBlock), 0, g_stream,
-                                                    (const uint4 *)buf, bytes / 16, sink);
+                                 if (g_probe_depth >= 16)
+                                     hipLaunchKernelGGL(stream_probe_kernel<16>, dim3(grid), dim3(kBlock), 0, g_stream,
+                                                        (const uint4 *)buf, bytes / 16, sink);
+                                 else
+                                     hipLaunchKernelGGL(stream_probe_kernel<4>, dim3(grid), dim3(kBlock), 0, g_stream,
+                                                        (const uint4 *)buf, bytes / 16, sink);
                                  hipError_t e = hipGetLastError();
                                  return e == hipSuccess ? 0 : fail("stream_probe launch: %s", hipGetErrorString(e));
                              },

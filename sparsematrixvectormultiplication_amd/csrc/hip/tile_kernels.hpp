@@ -52,9 +52,9 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 constexpr int kTileBlock = 512;      // threads per workgroup (8 wavefronts)
 constexpr int kTileWaves = kTileBlock / 64;
 constexpr int kTileChunkMax = 4096;  // padding behind the entry arrays (the plan's chunk, entries per pass at most, is 2048)
-constexpr int kTileRowsMax = 16384;  // rows per block at most (local row fits the key's 14 bits)
+constexpr int kTileRowsMax = 32768;  // rows per block at most (local row fits the key's 15 bits; fp64 blocks stop at what the LDS takes)
 constexpr int kTileHead = 0x8000;    // key bit: first entry of its row in this pass
-constexpr int kTileRowMask = 0x3fff;
+constexpr int kTileRowMask = 0x7fff;
 // The passes of a PACKED plan (pass_desc.w bit 30; all of them or none) store their entries packed: the column word holds
 // head << 31 | local row << 14 | (column - first staged column) and there is no key array --
 // 4 + sizeof(T) bytes per entry, CSR's own, instead of 6 + sizeof(T).

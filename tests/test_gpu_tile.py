@@ -38,7 +38,7 @@ class tuned:
     def __exit__(self, *exc):
         defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 4, "stream_kind": -1,
                     "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1, "tile_places": 0,
-                    "tile_streams": 1, "tile_fit": 1, "tile_plan_on_device": 1, "place_tries": 8, "tile_min_pass": 256, "tile_mid": 1}
+                    "tile_streams": 1, "tile_fit": 1, "tile_plan_on_device": 1, "place_tries": 12, "tile_min_pass": 256, "tile_mid": 1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 

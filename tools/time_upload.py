@@ -80,5 +80,5 @@ for name, make in (("power-law 2^24 fp32", lambda: synth.powerlaw()), ("road-lik
               f"digest {hash(tuple(d.tile_digest())) & 0xffffffff:08x})", flush=True)
         d.close()
     set_tuning("tile_plan_on_device", 1)
-    set_tuning("place_tries", 8)
+    set_tuning("place_tries", 12)
     del rp_, col_, val_
