@@ -108,6 +108,8 @@ typedef struct {
     float place_first_us;  /* kernel time at the placement hipMalloc gave first */
     float place_best_us;   /* ... at the placement the handle kept */
     unsigned long long val_address; /* where the value array lies now (placement record of a bench line) */
+    long long tile_expanded_entries; /* CSR: entry slots of a tile plan with gather passes that run on an expanded x (tile_expand
+                                        writes every entry's x value in entry order, csr_tile streams it: "tile_expand") */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -152,7 +154,7 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     row) to the split-row kernels (one workgroup per row piece) instead of leaving each to one lane
  *     "stream_tile"   -1 (auto) | 0 | 1   build the 2-D tile plan (csr_tile) when the matrix gets no x-window plan;
  *                     "tile_rows" 0 (auto: 32 KiB of accumulators for banded matrices, as many rows as the LDS takes for
- *                     scattered ones: 16128 fp64 / 32512 fp32) | a multiple of 256 in 256..32768 rows per block; "tile_lmax" (1024) longest row kept in
+ *                     scattered ones: 16128 fp64 / 32512 fp32) | a multiple of 256 in 256..32768 rows per block; "tile_lmax" (1536) longest row kept in
  *                     the ordinary tiles; "tile_density" (4) columns per entry up to which a pass is staged in LDS;
  *                     "tile_balance" 1 | 0 row blocks of equal entry / row counts; "tile_long" 1 | 0 | 2 a tile plan of
  *                     their own for the rows beyond tile_lmax (0: split-row kernels, 2: however few they are);
@@ -163,11 +165,14 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
+ *                     "tile_expand" -1 | 0 | 1 (read at upload and at launch) a tile plan with gather passes runs on an
+ *                         expanded x -- auto: from 2^22 entries on when under a tenth of them are staged; 0 never; 1 always
  *                     "tile_gather_ahead" 0 | 1 (read at launch) plans with gather passes send a pass's gathers out one pass
  *                     early (twice as many in flight per CU) -- measured to buy nothing (1113 vs 1108 us on config 5, 514.9 vs
  *                     514.8 on uniformly random columns: profiles/r3_ab_gather_ahead.txt), hence off;
- *                     "tile_mid" 1 | 0 a scattered plan gives its rows of more than 128 entries (up to tile_lmax) a tier of their
- *                     own -- compacted, blocks as tall as the LDS takes, every pass staged -- when they hold >= 2^22 entries;
+ *                     "tile_mid" 1 | 0 a scattered plan gives its rows of more than "tile_mid_lo" entries (0 = auto: 48 for fp32,
+ *                     128 for fp64; up to tile_lmax) a tier of their own -- compacted, blocks as tall as the LDS takes, every
+ *                     pass staged -- when they hold >= 2^22 entries;
  *                     "tile_plan_on_device" 1 | 0 the plan is built by kernels from the CSR arrays in HBM (round 3) or by host
  *                     threads; the two builders give the same bytes;
  *                     "tile_pack" 1 | 0 banded matrices get the PACKED plan (every pass cut at the 32 KiB window and
@@ -402,6 +407,17 @@ int spmv_hip_csr_power_iterate(spmv_csr_dev *m, int variant, int iters, const in
 int spmv_hip_csr_cg(spmv_csr_dev *m, int variant, int iters, const int *bounds, int use_halo, const void *b_host,
                     void *x_host, double *rr_hist, float *ms_total);
 int spmv_hip_csr_split_interior(spmv_csr_dev *m, long long *counts);
+/* N4 overlap below block granularity (round 3).  On a KKT-coupled cut every block also lists lines of the coupling block,
+ * which another rank owns: no interior BLOCKS -- but 13 of a row's 28 entries have their column in the rank's own range.
+ *   spmv_hip_csr_split_columns   splits the handle's entries by column into two sub-handles over the same rows: [col_lo,
+ *                                col_hi) = the rank's own range of x; counts[2] (optional): entries inside / outside
+ *                                (spmv_hip_comm_halo_setup calls it with the rank's bounds; "halo_split" 0: not)
+ *   spmv_hip_csr_run_split       part 0: y = A_own x (reads nothing of x outside the range: it can run while the halo
+ *                                travels); part 1: y += A_halo x.  0 then 1 = the handle's product up to the order in
+ *                                which a row's two partial sums are added (a fixed order: reproducible)
+ * spmv_hip_csr_power_iterate_halo uses the column split where halo setup made one. */
+int spmv_hip_csr_split_columns(spmv_csr_dev *m, int col_lo, int col_hi, long long *counts);
+int spmv_hip_csr_run_split(spmv_csr_dev *m, int part, const void *d_x, void *d_y, void *stream);
 int spmv_hip_csr_run_part(spmv_csr_dev *m, int part, const void *d_x, void *d_y, void *stream);
 int spmv_hip_csr_needed_ranges(const spmv_csr_dev *m, int max_ranges, int *ranges, int *count);
 int spmv_hip_halo_plan(int ranks, int rank, const int *bounds, const int *counts, const int *ranges, int stride,

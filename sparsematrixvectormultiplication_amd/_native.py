@@ -57,7 +57,7 @@ class DevInfo(C.Structure):
                 ("tile_staged_cols", C.c_longlong), ("tile_remainder_entries", C.c_longlong),
                 ("tile_mid_rows", C.c_int), ("tile_mid_items", C.c_int), ("tile_mid_entries", C.c_longlong),
                 ("place_tries", C.c_int), ("place_first_us", C.c_float), ("place_best_us", C.c_float),
-                ("val_address", C.c_ulonglong)]
+                ("val_address", C.c_ulonglong), ("tile_expanded_entries", C.c_longlong)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -213,6 +213,8 @@ _PROTOTYPES = {
                                   c_float_p]),
     "spmv_hip_csr_needed_ranges": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
     "spmv_hip_csr_split_interior": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    "spmv_hip_csr_split_columns": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
+    "spmv_hip_csr_run_split": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmv_hip_csr_run_part": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmv_hip_halo_plan": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, C.c_int, C.c_int, c_int_p, c_int_p,
                                      c_int_p, c_int_p]),

@@ -671,7 +671,17 @@ static int spmv_hip_comm_halo_setup_body(spmv_csr_dev *m, const int *bounds) {
     } while (0);
     (void)hipFree(d_all);
     // which of the handle's blocks can run while the halo is travelling
-    if (!rc) rc = spmv_hip_csr_split_interior(m, nullptr);
+    long long by_blocks[4] = {0, 0, 0, 0};  // interior / boundary blocks, interior / boundary entries
+    if (!rc) rc = spmv_hip_csr_split_interior(m, by_blocks);
+    // ... and, below block granularity (round 3), which ENTRIES: on a KKT-coupled cut every block also lists lines of the
+    // coupling block, which another rank owns (0 % interior blocks), but 13 of a row's 28 entries have their column in
+    // the rank's own range -- the handle split by column gives those their own launch ("halo_split" 0: blocks only)
+    // Only where the blocks leave most of the product waiting: the column split costs a second pass over the rows
+    // (fem-large cut 8 ways: blocks 20.0 + 4.7 us with 94 % interior, columns 20.2 + 7.4; the KKT cut: blocks 0 + 24,
+    // columns 14.3 + 18.5 -- profiles/r3_halo_shares.md)
+    const bool blocks_do = by_blocks[2] >= by_blocks[3];  // at least half of the entries in interior blocks
+    if (!rc && g_halo_split && g_comm_size > 1 && !blocks_do && !m->tiles_only && m->col && m->val)
+        rc = spmv_hip_csr_split_columns(m, bounds[g_comm_rank], bounds[g_comm_rank + 1], nullptr);
     return rc;
 }
 
@@ -755,14 +765,20 @@ int power_iterations_halo(spmv_csr_dev *m, int variant, int iters, double *d_par
     const long long n = m->M_local;
     const int grid = (int)std::max<long long>(1, std::min<long long>(kNormBlocks, (n + kBlock - 1) / kBlock));
     T *y_own = (T *)m->y + m->row0, *x_own = (T *)m->x + m->row0;
-    const bool overlap = g_comm && m->have_split && g_halo_overlap && (variant == SPMV_CSR_AUTO || variant == SPMV_CSR_STREAM);
+    const bool fast_path = variant == SPMV_CSR_AUTO || variant == SPMV_CSR_STREAM;
+    // the column split (own_part / halo_part) replaces the block split where halo setup made one: the product is then
+    // ALWAYS the two launches, overlapped or not -- the same bits either way
+    const bool col_split = g_comm && m->own_part && m->halo_part && fast_path;
+    const bool overlap = g_comm && (m->have_split || col_split) && g_halo_overlap && fast_path;
     bool in_flight = false;  // a halo exchange of the current x is under way on the second stream
     for (int i = 0; i < iters; ++i) {
-        if (overlap) {
-            if (csr_launch_part(m, 0, m->x, m->y, g_stream)) return -1;  // interior: own x only
+        if (overlap || col_split) {
+            // interior: own x only
+            if (col_split ? csr_launch_split(m, 0, m->x, m->y, g_stream) : csr_launch_part(m, 0, m->x, m->y, g_stream)) return -1;
             if (in_flight) HIP_TRY(hipStreamWaitEvent(g_stream, arrived, 0));
             in_flight = false;
-            if (csr_launch_part(m, 1, m->x, m->y, g_stream)) return -1;  // boundary blocks + split rows
+            // the rest: boundary blocks + split rows / the entries whose columns other ranks own
+            if (col_split ? csr_launch_split(m, 1, m->x, m->y, g_stream) : csr_launch_part(m, 1, m->x, m->y, g_stream)) return -1;
         } else {
             if (csr_launch_any(m, variant, m->x, m->y, g_stream)) return -1;
         }

@@ -135,7 +135,7 @@ struct TileBuild {
     bool lt_packed = false;  // ... the long rows' tiles
     std::vector<int4> tile_pieces, tile_long, lt_work;
     std::vector<int> lt_rows, lt_item_first;
-    // the middle tier of a scattered matrix (rows of kTileMidLo < entries <= tile_lmax): the same kind of plan
+    // the middle tier of a scattered matrix (rows of g_tile_mid_lo < entries <= tile_lmax): the same kind of plan
     TilePlan<T> mtiles;
     bool have_mid_tiles = false, mt_packed = false;
     std::vector<int4> mt_work;
@@ -198,7 +198,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
                              pos_bits, plan, pack, target, min_pass);
     };
     std::shared_ptr<TileDevArrays<T>> probe_arrays;
-    int lmax_eff = g_tile_lmax;  // longest row of the ordinary tiles (kTileMidLo once a middle tier is decided on)
+    int lmax_eff = g_tile_lmax;  // longest row of the ordinary tiles (g_tile_mid_lo once a middle tier is decided on)
     auto build_rows = [&](int rows, int s0, int rpb, bool pack, long long target, int min_pass, TilePlan<T> &plan,
                           std::shared_ptr<TileDevArrays<T>> &arrays) {
         return build_at(rows, row_begin + s0, row_len + s0, din ? din->row_begin + s0 : nullptr, din ? din->row_len + s0 : nullptr, rpb,
@@ -246,17 +246,21 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
     trace.mark("sample probes");
     tb.packed = want_pack && !tb.scattered;
     // The middle tier (round 3).  In a scattered plan every entry is a gathered value, and the gathers are what the
-    // kernel waits for (config 5: 0.91 of 1.19 ms for the rows of up to 1024 entries).  Rows of more than kTileMidLo
+    // kernel waits for (config 5: 0.91 of 1.19 ms for the rows of up to 1024 entries).  Rows of more than mid_lo
     // entries, compacted into blocks as tall as the LDS takes (16384 fp32 rows), put enough entries into every
     // 32 KiB column range for the PACKED kernel: their x look-ups move to LDS like the long rows' -- when there are
     // enough of them (2^22 entries) for the extra launch and its slabs to pay.
     bool want_mid = false;
-    if (tb.scattered && g_tile_mid && g_tile_long && !g_tile_rows && g_tile_lmax > kTileMidLo && g_tile_pack) {
+    // where the tier starts: the taller the blocks (fp32: 32512 rows, fp64: 16128), the shorter the rows that still fill
+    // a column range -- config 5 (fp32): 1051 us from 128 entries on, 1031 from 96, 1023 from 64, 1014 from 48, 1046 from
+    // 32 (profiles/r3_sweep_mid_lo.txt)
+    const int mid_lo = g_tile_mid_lo > 0 ? g_tile_mid_lo : sizeof(T) == 4 ? 48 : 128;
+    if (tb.scattered && g_tile_mid && g_tile_long && !g_tile_rows && g_tile_lmax > mid_lo && g_tile_pack) {
         long long mid_entries = 0;
         for (int r = 0; r < Ml; ++r)
-            if (row_len[r] > kTileMidLo && row_len[r] <= g_tile_lmax) mid_entries += row_len[r];
+            if (row_len[r] > mid_lo && row_len[r] <= g_tile_lmax) mid_entries += row_len[r];
         want_mid = mid_entries >= (4LL << 20);
-        if (want_mid) lmax_eff = kTileMidLo;
+        if (want_mid) lmax_eff = mid_lo;
     }
     // Mid-size matrices (fewer rows than kTileMinRows, but entries for four full passes on every place): only a
     // band of dense rows pays -- the packed plan, with blocks thin enough to give every place one (their slices stay
@@ -352,7 +356,7 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
                 }
                 return build_at(rows, begin_h, len_h, d_begin, d_len, rpb, lmax, pos_bits, pack, 0, 0, plan, tb.mtiles_dev);
             },
-            kTileMidLo, g_tile_lmax, 17, scattered_rows_max);
+            mid_lo, g_tile_lmax, 17, scattered_rows_max);
     if (want_mid && tb.have_tiles && (!tb.have_mid_tiles || !tb.mt_packed)) {
         // the tier did not come about (its passes would average fewer than 256 entries, or its build failed): the plan
         // without one, from the start -- the ordinary tiles then take the rows up to tile_lmax again
@@ -385,7 +389,9 @@ int tile_allow_lds() {
     static int done_for_device = -1;
     const bool done = done_for_device == g_device;
     if (done) return 0;
-    const void *fns[6] = {(const void *)csr_tile<T, false, 2048, kTileTrips, false>, (const void *)csr_tile<T, true, 2048, kTileTrips, false>,
+    constexpr int kXpTrips = 2048 * (int)sizeof(T) / kTileTripBytes;  // the expanded plans' instantiation
+    const void *fns[8] = {(const void *)csr_tile<T, false, 2048, kXpTrips, true>, (const void *)csr_tile<T, true, 2048, kXpTrips, true>,
+                          (const void *)csr_tile<T, false, 2048, kTileTrips, false>, (const void *)csr_tile<T, true, 2048, kTileTrips, false>,
                           (const void *)csr_tile<T, false, 2048, kTileTrips, true>, (const void *)csr_tile<T, true, 2048, kTileTrips, true>,
                           (const void *)csr_tile<T, false, 2048, kTileTrips, false, true>,
                           (const void *)csr_tile<T, true, 2048, kTileTrips, false, true>};
@@ -516,6 +522,30 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
                                rows.size() * 8;
         }
     };
+    // a plan whose passes gather (scattered columns: next to none of them dense enough to stage) runs on an expanded x:
+    // tile_expand walks the entries slice by slice of x and writes every entry's value into its pass's segment of x',
+    // which csr_tile<.., PACK> stages as that pass's window (tile_kernels.hpp).  The same products in the same order:
+    // the same bits as the gather passes.
+    // auto: fp32 plans from 2^22 entries on with fewer than a tenth of them in staged passes -- an fp64 gather brings twice
+    // the bytes per line and the expansion moves twice the bytes per entry: uniformly random columns, 4 M rows x 20, fp64
+    // 519 us with gather passes, 665 us expanded; config 5's short rows (fp32) 491 -> 405 us (profiles/r3_ab_expand.txt)
+    // ("tile_expand" 0: never, 1: always)
+    if (!rc && tb.have_tiles && !tb.packed && m->tcol && m->tile_padded > 0 &&
+        (g_tile_expand > 0 || (g_tile_expand < 0 && sizeof(T) == 4 && m->tile_entries >= (1 << 22) &&
+                               m->tile_staged * 10 <= m->tile_entries))) {
+        const size_t slots = (size_t)m->tile_padded;
+        m->expansion = new (std::nothrow) TileExpansion();
+        if (!m->expansion) return fail("csr_upload: out of host memory");
+        std::string err;
+        if (tile_build_expansion<T>(m->N, m->tcol, m->tkey, slots, m->tile_pass, (int)tb.tiles.spass.size(), g_stream, *m->expansion, err) < 0)
+            return fail("%s", err.c_str());
+        const size_t xe_bytes = (slots + kTileChunkMax) * sizeof(T);
+        hipError_t e = hipMalloc(&m->xe, xe_bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(m->xe, 0, xe_bytes, g_stream);
+        if (e != hipSuccess) return fail("hipMalloc(expanded x) failed: %s", hipGetErrorString(e));
+        m->device_bytes += xe_bytes + (slots + 64) * 6 + (slots + kTileChunkMax) * 4 + tb.tiles.spass.size() * 16 +
+                           (size_t)m->expansion->chunks * 16;
+    }
     if (!rc && tb.have_long_tiles) upload_tier(tb.ltiles, tb.ltiles_dev.get(), tb.lt_rows, tb.lt_work, tb.lt_item_first, tb.lt_packed, m->lt);
     if (!rc && tb.have_mid_tiles) upload_tier(tb.mtiles, tb.mtiles_dev.get(), tb.mt_rows, tb.mt_work, tb.mt_item_first, tb.mt_packed, m->mt);
     return rc;
@@ -1440,6 +1470,8 @@ extern "C" int spmv_hip_csr_upload_matrix(const CSRMatrix *csr, spmv_csr_dev **o
 
 extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     if (!m) return;
+    spmv_hip_csr_free(m->own_part);
+    spmv_hip_csr_free(m->halo_part);
     for (auto &r : m->relocs) {  // relocated arrays: the field points into r.raw
         *r.field = nullptr;
         release_relocated(r);
@@ -1490,6 +1522,8 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->tcol);
     (void)hipFree(m->tkey);
     (void)hipFree(m->tval);
+    (void)hipFree(m->xe);
+    delete m->expansion;
     (void)hipFree(m->tile_long_rows);
     (void)hipFree(m->tile_pieces);
     (void)hipFree(m->long_rows);
@@ -1718,6 +1752,7 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->place_first_us = m->place_first_us;
     out->place_best_us = m->place_best_us;
     out->val_address = (unsigned long long)(uintptr_t)m->val;
+    out->tile_expanded_entries = m->xe && m->expansion ? (long long)m->expansion->entries : 0;
     out->stream_kernel = m->local_blocks > 0 ? 1 : m->tile_blocks > 0 ? 3
                          : ((m->stream_cap == 4096 || m->stream_cap == 2048) && m->M_local > 0 &&
                             m->nz < (long long)m->M_local * (m->stream_cap / kBlock)) ? 2 : 0;
@@ -1729,6 +1764,11 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
                             4LL * m->tile_blocks +
                             std::max<long long>(0, m->nz - m->tile_entries - m->tile_rem_entries - m->lt.entries - m->mt.entries) * (vb + 4) +
                             m->tile_rem_entries * (vb + 4) + 16LL * m->tile_num_pieces + vb * m->M_local + vb * m->N;
+        // an expanded plan: tile_expand reads 2 + 4 bytes per entry and writes its x value, csr_tile reads that value as
+        // its window and a packed column word where it read column and key; every chunk copies its 32 KiB slice of x
+        // (out of L2 mostly)
+        if (m->xe && m->expansion)
+            out->stream_bytes += (long long)m->expansion->entries * (2 * vb + 4) + 16LL * m->expansion->chunks;
         for (const spmv_csr_dev::long_tiles *tier : {&m->lt, &m->mt})  // entries, descriptors, slabs written and read
             out->stream_bytes += tier->padded * (vb + 6) - (tier->packed ? 2 : 0) * tier->staged + 16LL * tier->passes +
                                  2 * vb * (long long)tier->items * tier->rows_per_block;
@@ -1846,7 +1886,26 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                        m->tile_streams, m->tile_rows, stage_ok, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,       \
                        m->tile_block_row, m->tile_block_pass, m->tile_pass, m->tcol, m->tkey, (const T *)m->tval,        \
                        m->tile_stream_block, m->tile_sblock_rows, x, y)
-                    if (m->tile_packed) { if (which) SPMV_TILE(true, true); else SPMV_TILE(false, true); }
+                    // an expanded plan: x into the passes' segments first, then the packed kernel over x' (16-byte pieces of
+                    // x: aligned x only)
+                    const bool expanded = m->xe && m->expansion && m->expansion->chunks > 0 && stage_ok && g_tile_expand != 0;
+                    if (expanded) {
+                        hipLaunchKernelGGL((tile_expand<T>), dim3(m->expansion->chunks), dim3(kExpandBlock), 0, s, m->N, g_tile_probe,
+                                           m->expansion->chunk, m->expansion->lcol, m->expansion->dest, x, (T *)m->xe);
+                        // (a pass's window is its own segment: 2048 values at most, one staging trip in fp32, two in fp64)
+                        constexpr int kXpTrips = 2048 * (int)sizeof(T) / kTileTripBytes;
+                        const size_t xlds = std::max((size_t)m->tile_lds_min, (size_t)kTileSlotBytes + (size_t)m->tile_rows * sizeof(T) +
+                                                                                  (size_t)kXpTrips * kTileTripBytes);
+#define SPMV_TILE_XP(NT)                                                                                               \
+    hipLaunchKernelGGL((csr_tile<T, NT, 2048, kXpTrips, true>), dim3((m->tile_streams + 7) / 8 * 8), dim3(kTileBlock), xlds, s, \
+                       m->tile_streams, m->tile_rows, 1, g_tile_probe, (const int4 *)nullptr, (T *)nullptr,              \
+                       m->tile_block_row, m->tile_block_pass, m->expansion->pass, m->expansion->words,                   \
+                       (const unsigned short *)nullptr, (const T *)m->tval, m->tile_stream_block, m->tile_sblock_rows,   \
+                       (const T *)m->xe, y)
+                        if (which) SPMV_TILE_XP(true); else SPMV_TILE_XP(false);
+#undef SPMV_TILE_XP
+                    }
+                    else if (m->tile_packed) { if (which) SPMV_TILE(true, true); else SPMV_TILE(false, true); }
                     else if (g_tile_gather_ahead) { if (which) SPMV_TILE_GA(true); else SPMV_TILE_GA(false); }  // gathers one pass early
                     else { if (which) SPMV_TILE(true, false); else SPMV_TILE(false, false); }
 #undef SPMV_TILE_GA
@@ -2063,6 +2122,111 @@ static int csr_split_interior_body(spmv_csr_dev *m, long long *counts) {
 
 extern "C" int spmv_hip_csr_split_interior(spmv_csr_dev *m, long long *counts) {
     return guarded("csr_split_interior", [&] { return csr_split_interior_body(m, counts); });
+}
+
+// ---- N4 overlap below block granularity: the column split
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void add_rows(long long n, const T *__restrict__ t, T *__restrict__ y) {
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) y[k] += t[k];
+}
+
+template <typename T>
+int csr_split_columns_impl(spmv_csr_dev *m, int col_lo, int col_hi, long long *counts) {
+    spmv_hip_csr_free(m->own_part);
+    spmv_hip_csr_free(m->halo_part);
+    m->own_part = m->halo_part = nullptr;
+    m->own_entries = m->halo_entries = 0;
+    const int Ml = m->M_local;
+    const size_t nz = (size_t)m->nz;
+    std::vector<int> rp((size_t)Ml + 1), col(nz);
+    std::vector<T> val(nz);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(rp.data(), m->row_ptr, rp.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (nz) HIP_TRY(hipMemcpy(col.data(), m->col, nz * sizeof(int), hipMemcpyDeviceToHost));
+    if (nz) HIP_TRY(hipMemcpy(val.data(), m->val, nz * sizeof(T), hipMemcpyDeviceToHost));
+    // two CSR matrices over the same rows: entries keep their order inside a row
+    std::vector<int> rp_own((size_t)m->M_total + 1, 0), rp_halo((size_t)m->M_total + 1, 0), c_own, c_halo;
+    std::vector<T> v_own, v_halo;
+    c_own.reserve(nz);
+    v_own.reserve(nz);
+    for (int r = 0; r < Ml; ++r) {
+        for (int e = rp[(size_t)r]; e < rp[(size_t)r + 1]; ++e) {
+            if (col[(size_t)e] >= col_lo && col[(size_t)e] < col_hi) {
+                c_own.push_back(col[(size_t)e]);
+                v_own.push_back(val[(size_t)e]);
+            } else {
+                c_halo.push_back(col[(size_t)e]);
+                v_halo.push_back(val[(size_t)e]);
+            }
+        }
+        rp_own[(size_t)m->row0 + r + 1] = (int)c_own.size();
+        rp_halo[(size_t)m->row0 + r + 1] = (int)c_halo.size();
+    }
+    for (int r = m->row0 + Ml; r < m->M_total; ++r) {  // rows behind the handle's block: empty
+        rp_own[(size_t)r + 1] = (int)c_own.size();
+        rp_halo[(size_t)r + 1] = (int)c_halo.size();
+    }
+    m->own_entries = (long long)c_own.size();
+    m->halo_entries = (long long)c_halo.size();
+    if (counts) {
+        counts[0] = m->own_entries;
+        counts[1] = m->halo_entries;
+    }
+    if (c_halo.empty()) return 0;  // nothing comes from other ranks: the handle itself is the interior (same bits as ever)
+    // (the sub-handles are ordinary handles: plans, block cuts, AUTO -- but no placement search of their own)
+    const int keep = g_place_tries;
+    g_place_tries = 0;
+    int rc = csr_upload_impl<T>(m->M_total, m->N, rp_own.data(), c_own.data(), v_own.data(), m->row0, m->row0 + Ml, &m->own_part);
+    if (!rc) rc = csr_upload_impl<T>(m->M_total, m->N, rp_halo.data(), c_halo.data(), v_halo.data(), m->row0, m->row0 + Ml, &m->halo_part);
+    g_place_tries = keep;
+    if (rc) {
+        spmv_hip_csr_free(m->own_part);
+        spmv_hip_csr_free(m->halo_part);
+        m->own_part = m->halo_part = nullptr;
+        return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// Split the handle's entries by column: [col_lo, col_hi) = the rank's own range of x.  counts[2] (optional): entries
+// whose column lies inside / outside.  Afterwards spmv_hip_csr_run_split(part 0) computes y = A_own x -- it reads
+// nothing of x outside [col_lo, col_hi) -- and part 1 adds A_halo x; 0 then 1 = the handle's product up to the
+// order in which a row's two partial sums are added.  A handle without outside entries keeps no sub-handles.
+extern "C" int spmv_hip_csr_split_columns(spmv_csr_dev *m, int col_lo, int col_hi, long long *counts) {
+    if (need_device()) return -1;
+    if (!m || col_lo < 0 || col_hi < col_lo || col_hi > m->N) return fail("csr_split_columns: bad arguments");
+    if (m->tiles_only || !m->col || !m->val) return fail("csr_split_columns: the handle does not hold its CSR arrays");
+    return guarded("csr_split_columns", [&] {
+        return m->value_bytes == 8 ? csr_split_columns_impl<double>(m, col_lo, col_hi, counts)
+                                   : csr_split_columns_impl<float>(m, col_lo, col_hi, counts);
+    });
+}
+
+int csr_launch_split(const spmv_csr_dev *m, int part, const void *x, void *y, hipStream_t s) {
+    if (!m->own_part || !m->halo_part) {  // no split (nothing comes from outside): everything is part 0
+        return part == 0 ? csr_launch_any(m, SPMV_CSR_AUTO, x, y, s) : 0;
+    }
+    if (part == 0) return csr_launch_any(m->own_part, SPMV_CSR_AUTO, x, y, s);
+    // y_own += A_halo x: the product into the sub-handle's own y, then one pass over this rank's rows
+    if (csr_launch_any(m->halo_part, SPMV_CSR_AUTO, x, m->halo_part->y, s)) return -1;
+    const long long n = m->M_local;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(2048, (n + kBlock - 1) / kBlock));
+    if (m->value_bytes == 8)
+        hipLaunchKernelGGL((add_rows<double>), dim3(grid), dim3(kBlock), 0, s, n, (const double *)m->halo_part->y + m->row0, (double *)y + m->row0);
+    else
+        hipLaunchKernelGGL((add_rows<float>), dim3(grid), dim3(kBlock), 0, s, n, (const float *)m->halo_part->y + m->row0, (float *)y + m->row0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int spmv_hip_csr_run_split(spmv_csr_dev *m, int part, const void *d_x, void *d_y, void *stream) {
+    if (need_device()) return -1;
+    if (!m || (part != 0 && part != 1)) return fail("csr_run_split: bad arguments");
+    return csr_launch_split(m, part, d_x ? d_x : m->x, d_y ? d_y : m->y, stream ? (hipStream_t)stream : g_stream);
 }
 
 extern "C" int spmv_hip_csr_run_part(spmv_csr_dev *m, int part, const void *d_x, void *d_y, void *stream) {

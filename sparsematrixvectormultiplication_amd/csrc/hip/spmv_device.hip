@@ -90,12 +90,14 @@ int g_plan_on_device = 1;
 int g_stream_kind = -1;
 int g_stream_tile = -1;
 int g_tile_rows = 0;
-int g_tile_lmax = 1024;
+int g_tile_lmax = 1536;  // (1024 until round 3: config 5 1016 us at 1024, 1000 at 1536, 1001 at 2048; with the expanded short rows 942 / 927 / 930)
 int g_tile_density = 4;
 int g_tile_plan_on_device = 1;
 int g_place_tries = 12;
 int g_tile_mid = 1;
+int g_tile_mid_lo = 0;  // 0: auto (48 entries for fp32, 128 for fp64)
 int g_tile_gather_ahead = 0;  // measured: no gain (profiles/r3_ab_gather_ahead.txt)
+int g_tile_expand = -1;       // plans with gather passes run on an expanded x (tile_expand + csr_tile<.., XE>): auto
 int g_tile_probe = 0;
 int g_skew_rows = 1;
 int g_tile_fit = 1;
@@ -106,6 +108,7 @@ int g_tile_items = 1008;  // two rounds of the 512 places: 1.222 ms on the power
 int g_tile_pack = 1;
 int g_tile_long = 1;
 int g_halo_overlap = 1;
+int g_halo_split = 1;
 int g_tile_balance = 1;
 int g_pipe_wgs_per_cu = 5;
 int g_num_cus = 256;
@@ -230,6 +233,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         if (value != 0 && (value < 256 || value > kTileRowsMax || (value & 255)))
             return fail("set_tuning: tile_rows must be 0 (auto) or a multiple of 256 in 256..%d", kTileRowsMax);
         g_tile_rows = value;
+    } else if (!strcmp(key, "halo_split")) {
+        g_halo_split = value != 0;  // read by spmv_hip_comm_halo_setup
     } else if (!strcmp(key, "halo_overlap")) {
         g_halo_overlap = value != 0;
     } else if (!strcmp(key, "tile_pack")) {
@@ -261,6 +266,11 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
         g_probe_depth = value;
     } else if (!strcmp(key, "tile_gather_ahead")) {
         g_tile_gather_ahead = value != 0;  // read at launch
+    } else if (!strcmp(key, "tile_expand")) {
+        g_tile_expand = value < 0 ? -1 : value != 0;  // read at upload (the plan) and at launch (0: the gather passes)
+    } else if (!strcmp(key, "tile_mid_lo")) {
+        if (value != 0 && (value < 8 || value > 1024)) return fail("set_tuning: tile_mid_lo must be 0 (auto) or 8..1024");
+        g_tile_mid_lo = value;  // takes effect at the next upload
     } else if (!strcmp(key, "tile_mid")) {
         g_tile_mid = value != 0;  // takes effect at the next upload
     } else if (!strcmp(key, "place_tries")) {

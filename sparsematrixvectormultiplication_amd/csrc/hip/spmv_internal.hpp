@@ -38,6 +38,7 @@ extern int g_stream_block;    // threads per csr_stream workgroup
 extern int g_stream_nt;       // non-temporal loads for col/val in the gather stream kernels
 extern int g_local_nt;        // same for the x-window kernels: -1 = auto (off while the matrix fits the Infinity Cache)
 extern int g_stream_xcd;      // blocks per XCD run (xcd_chunked); 0 = default, -1 = one contiguous eighth per XCD
+extern int g_halo_split;      // halo setup splits the handle by columns (1) or by blocks only (0)
 extern int g_halo_overlap;    // power iteration with halo: exchange beside the interior blocks (1) or strictly in order (0)
 extern int g_gather_mode;     // all-gatherv: 0 = one ncclBroadcast per owner in a group, 1 = padded ncclAllGather + scatter
 extern int g_local_cap;       // stage of the x-window plan: 0 = auto, 1024 or 2048
@@ -63,7 +64,8 @@ extern int g_tile_balance;    // 1: row blocks of about equal entry counts (keep
 extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile plan of their own (compacted rows, work items, slabs)
 extern int g_tile_pack;       // 1: passes that can be staged store head | row | column offset in one 32-bit word (no key read)
 extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
-constexpr int kTileMidLo = 128;  // a scattered matrix's rows longer than this (up to tile_lmax) form the middle tier
+extern int g_tile_mid_lo;     // a scattered matrix's rows longer than this (up to tile_lmax) form the middle tier ("tile_mid_lo")
+extern int g_tile_expand;     // plans with gather passes: -1 auto, 0 never, 1 always: x expanded into entry order ahead of csr_tile ("tile_expand")
 extern int g_tile_gather_ahead;  // 1: plans with gather passes run the csr_tile instantiation that gathers one pass early
 extern int g_tile_mid;        // 1: scattered plans get that tier (when it holds >= 2^22 entries), 0: never
 extern int g_place_tries;     // other placements of the value array upload tries for large handles (0: none)
@@ -163,6 +165,9 @@ inline bool skew_cut(int nrows, int maxlen, int len) {
 }
 
 // ---------------------------------------------------------------- handles
+namespace spmv {
+struct TileExpansion;  // tile_plan_device.hpp
+}
 struct spmv_csr_dev {
     int value_bytes = 8;
     int M_local = 0, M_total = 0, N = 0, row0 = 0;
@@ -195,6 +200,11 @@ struct spmv_csr_dev {
     int *interior_ids = nullptr, *boundary_ids = nullptr;
     int num_interior = 0, num_boundary = 0;
     bool have_split = false;
+    // N4 overlap below block granularity (round 3): the handle's entries split by COLUMN -- own_part holds those whose
+    // column lies in the rank's own range of x (it can run before the halo has arrived), halo_part the rest; two
+    // sub-handles over the same rows, launched on this handle's vectors (spmv_hip_csr_split_columns)
+    spmv_csr_dev *own_part = nullptr, *halo_part = nullptr;
+    long long own_entries = 0, halo_entries = 0;
     bool tiles_only = false;  // a handle made of tile plans alone (the tile side of an HLL handle): STREAM only
     // csr_tile (2-D tiles: row-block accumulators in LDS x column passes), for matrices without an x-window plan
     int tile_blocks = 0;              // 0: no tiles
@@ -218,6 +228,10 @@ struct spmv_csr_dev {
     int *tcol = nullptr;              // [tile_padded + kTileChunkMax]
     unsigned short *tkey = nullptr;
     void *tval = nullptr;
+    // the expansion of x for a plan with gather passes (round 3; tile_kernels.hpp, XE): x value per tile entry, written
+    // by tile_expand ahead of every csr_tile launch of this handle, and what tile_expand walks
+    void *xe = nullptr;               // [tile_padded + kTileChunkMax]
+    spmv::TileExpansion *expansion = nullptr;
     // long-row tile plan: the rows beyond the tile limit, compacted into their own row blocks; a block's passes
     // are dealt out to several workgroups (work items), each leaves its accumulators in a slab
     struct long_tiles {
@@ -230,7 +244,7 @@ struct spmv_csr_dev {
         unsigned short *tkey = nullptr;
         void *tval = nullptr, *slab = nullptr;
     } lt, mt;  // lt: rows beyond tile_lmax (2048 compacted rows per block); mt (round 3): the MIDDLE tier of a scattered
-               // matrix, rows of kTileMidLo < entries <= tile_lmax in blocks as tall as the LDS takes, so that their
+               // matrix, rows of tile_mid_lo < entries <= tile_lmax in blocks as tall as the LDS takes, so that their
                // column ranges hold enough entries to be staged as well
     int4 *tile_long_rows = nullptr;   // rows beyond the tile limit {row, first slot, pieces, 0} ...
     int4 *tile_pieces = nullptr;      // ... and their pieces, cut at column stripes, stripe by stripe
@@ -310,6 +324,8 @@ int csr_tile_digest(const spmv_csr_dev *m, unsigned long long *out);  // spmv_cs
 int csr_launch_any(const spmv_csr_dev *m, int variant, const void *x, void *y, hipStream_t s);
 // part 0: the interior x-window blocks only; part 1: everything else (boundary blocks, split rows)
 int csr_launch_part(const spmv_csr_dev *m, int part, const void *x, void *y, hipStream_t s);
+// column split: part 0: y = A_own x (own range of x only); part 1: y += A_halo x (after the halo has arrived)
+int csr_launch_split(const spmv_csr_dev *m, int part, const void *x, void *y, hipStream_t s);
 int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_full, hipStream_t s);
 
 // ------------------------------------------------------------------ timing loops

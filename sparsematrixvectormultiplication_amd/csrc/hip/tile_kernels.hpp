@@ -531,6 +531,64 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
     }
 }
 
+// The EXPANSION of x for a plan with gather passes (round 3).  A 64-lane gather of scattered columns costs the texture
+// addresser 64 lines for 256 useful bytes, whether they hit L2 or not: config 5's short rows spent 315 of their 491 us
+// there.  An expanded plan gathers nothing: every pass owns a SEGMENT of a second vector x' with one value per entry --
+// the pass's x values, ordered by (32 KiB slice of x, row, column) -- and runs as a PACKED pass whose window is that
+// segment (csr_tile<.., PACK>, unchanged: the column word holds the entry's place in the segment).  tile_expand fills
+// x' ahead of every csr_tile launch, walking the plan's entries in SLICE order: a workgroup copies its slice of x to
+// LDS with coalesced loads, looks the columns up there, and writes the values to their segments -- the entries of one
+// (slice, pass) lie together in both orders, so the writes are runs, not single values.  The products and the order in
+// which a row's are added are those of the gather passes: the same bits.
+// x'[dest[k]] = x[slice * W + lcol[k]];  chunk = {slice, first k, entries, 0}: at most kExpandChunk entries of one slice.
+// (dest per entry is 4 of the kernel's 10 bytes per entry, and consecutive entries mostly have consecutive places: a
+// variant that stored one offset per RUN of such entries -- a start bit in lcol, the run numbered per wavefront with a
+// ballot -- read 6 bytes per entry and was SLOWER, 252 us against 189 on config 5's 63 M short-row entries: the offset
+// is a second, dependent trip to memory per entry.  With the places streamed in order the kernel runs at 108 us.)
+constexpr int kExpandBlock = 512;
+constexpr int kExpandChunk = 16384;
+template <typename T>
+constexpr int tile_slice_cols() {
+    return kTileTrips * kTileTripBytes / (int)sizeof(T);
+}
+template <typename T>
+__global__ __launch_bounds__(kExpandBlock) void tile_expand(int N, int probe, const int4 *__restrict__ chunk,
+                                                            const unsigned short *__restrict__ lcol, const unsigned *__restrict__ dest,
+                                                            const T *__restrict__ x, T *__restrict__ xe) {
+    constexpr int W = tile_slice_cols<T>(), kPer = 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) T xs[W];
+    const int4 c = chunk[blockIdx.x];
+    const int t = threadIdx.x;
+    const long long base = (long long)c.x * W;
+    const int wlen = (int)min((long long)W, (long long)N - base);
+    const int whole = wlen / kPer * kPer;
+    // (x is 16-byte aligned -- the launch checks -- and a slice begins at a multiple of 32 KiB)
+    const v4u *src = reinterpret_cast<const v4u *>(x + base);
+    for (int j = t * kPer; j < whole; j += kExpandBlock * kPer) *reinterpret_cast<v4u *>(xs + j) = src[j / kPer];
+    if (t < wlen - whole) xs[whole + t] = x[base + whole + t];
+    __syncthreads();
+    const unsigned short *lc = lcol + c.y;
+    const unsigned *de = dest + c.y;
+    const int n = c.z;
+    constexpr int U = 8;  // loads of U trips in flight before the first store
+    for (int i0 = 0; i0 < n; i0 += U * kExpandBlock) {
+        unsigned d[U];
+        int l[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kExpandBlock + t;
+            l[u] = i < n ? (int)stream_load<true>(lc + i) : 0;
+            // (probe, measurement only: bit 0 -- no dest read, the values go out in slice order, as a stream)
+            d[u] = (probe & 1) ? (unsigned)(c.y + i) : i < n ? stream_load<true>(de + i) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kExpandBlock + t;
+            if (i < n) xe[d[u]] = xs[l[u]];
+        }
+    }
+}
+
 // y[row_map[v]] = the sum of the slabs of virtual row v's block (long-row plans), in a fixed order: the block's
 // work items are cut into kFinishGroups contiguous groups, a thread adds one group's slabs in item order (loads
 // independent of each other: several in flight), then the groups' sums are added in group order.

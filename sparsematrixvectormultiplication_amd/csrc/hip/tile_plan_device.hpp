@@ -514,4 +514,184 @@ int tile_build_device(int M, int N, const TileDevInput<T> &in, const int *h_row_
     return 1;
 }
 
+// ---- the expansion plan of a tile plan with gather passes (tile_expand + csr_tile<.., PACK> over x', tile_kernels.hpp)
+namespace tile_dev {
+
+// pass_of[e] = the pass (index in `pass`) whose region holds slot e: a pass owns [d.x, d.x + round_up4(d.y))
+__global__ __launch_bounds__(256) void expand_pass_of(int passes, const int4 *__restrict__ pass, unsigned *__restrict__ pass_of) {
+    const int p = blockIdx.x;
+    if (p >= passes) return;
+    const int4 d = pass[p];
+    for (int i = threadIdx.x; i < ((d.y + 3) & ~3); i += 256) pass_of[d.x + i] = (unsigned)p;
+}
+// sort 1: key = first slot of the pass's region << 32 | slice of the entry's column (slots behind a pass's entries, and
+// slots no pass owns: all ones in the low word -- behind the pass's entries); payload = the slot.  Regions are disjoint
+// and cover every slot: a region occupies the same positions before and after the sort
+__global__ __launch_bounds__(256) void expand_keys(size_t n, const int *__restrict__ tcol, const unsigned *__restrict__ pass_of,
+                                                   const int4 *__restrict__ pass, int slice_shift, unsigned slices,
+                                                   unsigned long long *__restrict__ keys, unsigned *__restrict__ slot) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const unsigned p = pass_of[e];
+        unsigned lo = 0xffffffffu, region = (unsigned)e;  // (a slot no pass owns: a region of its own)
+        if (p != 0xffffffffu) {
+            const int4 d = pass[p];
+            region = (unsigned)d.x;
+            if ((long long)e < (long long)d.x + d.y) lo = min((unsigned)tcol[e] >> slice_shift, slices - 1);
+        }
+        keys[e] = ((unsigned long long)region << 32) | lo;
+        slot[e] = (unsigned)e;
+    }
+}
+// after sort 1 position q holds slot order1[q]: the entry's place in x' is q (a pass's region is the same in both
+// orders).  place[e] = q; the key of sort 2 = the slice (slots that are not entries: the last slice, expanded like
+// entries, read by nobody), payload q
+__global__ __launch_bounds__(256) void expand_places(size_t n, const unsigned long long *__restrict__ sorted, const unsigned *__restrict__ order1,
+                                                     unsigned slices, unsigned *__restrict__ place, unsigned *__restrict__ key2,
+                                                     unsigned *__restrict__ pos) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+        place[order1[q]] = (unsigned)q;
+        key2[q] = min((unsigned)sorted[q], slices - 1);
+        pos[q] = (unsigned)q;
+    }
+}
+// first[c] = the first sorted position whose slice is >= c (c = 0 .. slices)
+__global__ __launch_bounds__(256) void expand_starts(size_t n, const unsigned *__restrict__ sorted, unsigned slices, unsigned *__restrict__ first) {
+    const unsigned c = blockIdx.x * 256 + threadIdx.x;
+    if (c > slices) return;
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if (sorted[mid] < c) lo = mid + 1;
+        else hi = mid;
+    }
+    first[c] = (unsigned)lo;
+}
+// lcol[k] = the column of the entry that lives at x'[dest[k]], inside its slice
+__global__ __launch_bounds__(256) void expand_lcol(size_t n, const unsigned *__restrict__ slice_sorted, const unsigned *__restrict__ dest,
+                                                   const unsigned *__restrict__ order1, const int *__restrict__ tcol, int slice_shift,
+                                                   unsigned short *__restrict__ lcol) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const long long l = (long long)(unsigned)tcol[order1[dest[k]]] - ((long long)slice_sorted[k] << slice_shift);
+        lcol[k] = (unsigned short)max(0ll, min(l, (1ll << slice_shift) - 1));
+    }
+}
+// the packed column word of slot e: head << 31 | local row << 14 | place in the pass's segment of x'
+__global__ __launch_bounds__(256) void expand_words(size_t n, const unsigned short *__restrict__ tkey, const unsigned *__restrict__ place,
+                                                    const unsigned *__restrict__ pass_of, const int4 *__restrict__ pass,
+                                                    int *__restrict__ words) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const unsigned p = pass_of[e];
+        unsigned w = 0;
+        if (p != 0xffffffffu) {
+            const unsigned key = tkey[e];
+            w = ((key & (unsigned)kTileHead) << 16) | ((key & (unsigned)kTileRowMask) << kTilePackShift) |
+                ((place[e] - (unsigned)pass[p].x) & kTilePackColMask);
+        }
+        words[e] = (int)w;
+    }
+}
+// the packed plan's descriptors: the pass's own segment of x' as its window
+__global__ __launch_bounds__(256) void expand_pass_desc(int passes, const int4 *__restrict__ pass, int4 *__restrict__ out) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= passes) return;
+    const int4 d = pass[p];
+    out[p] = make_int4(d.x, d.y, d.x, max((d.y + 3) & ~3, 4) | kTilePassPacked | (d.w & kTilePassLast));
+}
+
+}  // namespace tile_dev
+
+// what tile_expand walks and what csr_tile<.., PACK> runs on, freed with the owner
+struct TileExpansion {
+    unsigned short *lcol = nullptr;  // [slots + pad] column inside the slice, slice order
+    unsigned *dest = nullptr;        // [slots + pad] the entry's place in x'
+    int4 *chunk = nullptr;           // [chunks] {slice, first, entries, 0}
+    int *words = nullptr;            // [slots + kTileChunkMax] packed column words, the plan's entry order
+    int4 *pass = nullptr;            // [passes] the plan's descriptors with the pass's segment of x' as window
+    int chunks = 0;
+    size_t entries = 0;
+    ~TileExpansion() {
+        (void)hipFree(lcol);
+        (void)hipFree(dest);
+        (void)hipFree(chunk);
+        (void)hipFree(words);
+        (void)hipFree(pass);
+    }
+};
+
+// 1: built; -1: HIP error (message through err).  tcol, tkey: the plan's arrays on the device, n slots; d_pass: its
+// descriptors (device, any order), passes of them.
+template <typename T>
+int tile_build_expansion(int N, const int *tcol, const unsigned short *tkey, size_t n, const int4 *d_pass, int passes, hipStream_t s,
+                         TileExpansion &ex, std::string &err) {
+    using namespace tile_dev;
+    UploadTrace trace("tile_build_expansion");
+    constexpr int W = tile_slice_cols<T>();
+    static_assert((W & (W - 1)) == 0, "slices are a power of two wide");
+    const int slice_shift = (int)bits_for((unsigned long long)W) - 1;
+    const unsigned slices = (unsigned)(((long long)std::max(N, 1) + W - 1) / W);
+    Scratch tmp;
+    auto bad = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return false;
+        err = std::string("expansion plan: ") + what + " failed: " + hipGetErrorString(e);
+        return true;
+    };
+    unsigned long long *keys_a, *keys_b;
+    unsigned *slot_a, *order1, *pass_of, *place, *key2_a, *key2_b, *pos_a, *first;
+    hipError_t e = tmp.alloc(&keys_a, n);
+    if (e == hipSuccess) e = tmp.alloc(&keys_b, n);
+    if (e == hipSuccess) e = tmp.alloc(&slot_a, n);
+    if (e == hipSuccess) e = tmp.alloc(&order1, n);
+    if (e == hipSuccess) e = tmp.alloc(&pass_of, n);
+    if (e == hipSuccess) e = tmp.alloc(&place, n);
+    if (e == hipSuccess) e = tmp.alloc(&key2_a, n);
+    if (e == hipSuccess) e = tmp.alloc(&key2_b, n);
+    if (e == hipSuccess) e = tmp.alloc(&pos_a, n);
+    if (e == hipSuccess) e = tmp.alloc(&first, (size_t)slices + 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&ex.dest, (n + 64) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&ex.lcol, (n + 64) * sizeof(unsigned short));
+    if (e == hipSuccess) e = hipMalloc((void **)&ex.words, (n + kTileChunkMax) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&ex.pass, (size_t)std::max(passes, 1) * sizeof(int4));
+    if (e == hipSuccess) e = hipMemsetAsync(pass_of, 0xff, n * sizeof(unsigned), s);
+    if (e == hipSuccess) e = hipMemsetAsync(ex.words + n, 0, (size_t)kTileChunkMax * sizeof(int), s);
+    if (bad(e, "allocation")) return -1;
+    if (passes > 0) hipLaunchKernelGGL(expand_pass_of, dim3(passes), dim3(256), 0, s, passes, d_pass, pass_of);
+    hipLaunchKernelGGL(expand_keys, dim3(4096), dim3(256), 0, s, n, tcol, pass_of, d_pass, slice_shift, slices, keys_a, slot_a);
+    size_t tmp_bytes = 0;
+    void *d_tmp = nullptr;
+    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, slot_a, order1, n, 0u, 64u, s);
+    if (e == hipSuccess) e = tmp.alloc((char **)&d_tmp, tmp_bytes);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, keys_a, keys_b, slot_a, order1, n, 0u, 64u, s);
+    if (bad(e, "sort by (pass, slice)")) return -1;
+    hipLaunchKernelGGL(expand_places, dim3(4096), dim3(256), 0, s, n, keys_b, order1, slices, place, key2_a, pos_a);
+    size_t tmp2_bytes = 0;
+    void *d_tmp2 = nullptr;
+    const unsigned end_bit = bits_for((unsigned long long)slices);
+    e = rocprim::radix_sort_pairs(nullptr, tmp2_bytes, key2_a, key2_b, pos_a, ex.dest, n, 0u, end_bit, s);
+    if (e == hipSuccess) e = tmp.alloc((char **)&d_tmp2, tmp2_bytes);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp2, tmp2_bytes, key2_a, key2_b, pos_a, ex.dest, n, 0u, end_bit, s);
+    if (bad(e, "sort by slice")) return -1;
+    hipLaunchKernelGGL(expand_starts, dim3((slices + 1 + 255) / 256), dim3(256), 0, s, n, key2_b, slices, first);
+    hipLaunchKernelGGL(expand_lcol, dim3(4096), dim3(256), 0, s, n, key2_b, ex.dest, order1, tcol, slice_shift, ex.lcol);
+    hipLaunchKernelGGL(expand_words, dim3(4096), dim3(256), 0, s, n, tkey, place, pass_of, d_pass, ex.words);
+    if (passes > 0) hipLaunchKernelGGL(expand_pass_desc, dim3((passes + 255) / 256), dim3(256), 0, s, passes, d_pass, ex.pass);
+    std::vector<unsigned> h_first((size_t)slices + 1);
+    e = hipMemcpyAsync(h_first.data(), first, h_first.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (bad(e, "keys, sorts, words")) return -1;
+    trace.mark("keys, two sorts, slice columns, packed words");
+    std::vector<int4> chunks;
+    for (unsigned c = 0; c < slices; ++c)
+        for (unsigned k = h_first[c]; k < h_first[(size_t)c + 1]; k += (unsigned)kExpandChunk)
+            chunks.push_back(make_int4((int)c, (int)k, (int)std::min<unsigned>((unsigned)kExpandChunk, h_first[(size_t)c + 1] - k), 0));
+    e = hipMalloc((void **)&ex.chunk, std::max<size_t>(1, chunks.size()) * sizeof(int4));
+    if (e == hipSuccess && !chunks.empty())
+        e = hipMemcpyAsync(ex.chunk, chunks.data(), chunks.size() * sizeof(int4), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (bad(e, "chunks")) return -1;
+    ex.chunks = (int)chunks.size();
+    ex.entries = n;
+    return 1;
+}
+
 }  // namespace spmv

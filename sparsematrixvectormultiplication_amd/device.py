@@ -322,6 +322,17 @@ class CsrDevice(_Handle):
         return dict(zip(("interior_blocks", "boundary_blocks", "interior_entries", "boundary_entries"),
                         (int(v) for v in counts)))
 
+    def split_columns(self, col_lo: int, col_hi: int) -> dict:
+        """Split the handle's entries by column ([col_lo, col_hi) = the rank's own range of x) into two sub-handles
+        (spmv_hip_csr_split_columns); returns the entry counts inside / outside the range."""
+        counts = (C.c_longlong * 2)()
+        _check(nat.lib().spmv_hip_csr_split_columns(self.h, int(col_lo), int(col_hi), counts), "spmv_hip_csr_split_columns")
+        return {"own_entries": int(counts[0]), "halo_entries": int(counts[1])}
+
+    def run_split(self, part: int):
+        """part 0: y = A_own x (own range of x only); part 1: y += A_halo x (asynchronous on the library stream)."""
+        _check(nat.lib().spmv_hip_csr_run_split(self.h, int(part), None, None, None), "spmv_hip_csr_run_split")
+
     def run_part(self, part: int):
         """part 0: interior blocks only; part 1: the rest (asynchronous on the library stream)."""
         _check(nat.lib().spmv_hip_csr_run_part(self.h, int(part), None, None, None), "spmv_hip_csr_run_part")

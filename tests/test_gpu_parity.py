@@ -585,6 +585,43 @@ def test_x_window_plan_keeps_going_past_a_few_scattered_rows(gpu, oracle):
                     assert np.max(np.abs(y.astype(np.float64) - ref)) / np.max(np.abs(ref)) <= FP32_NORMWISE_RTOL
 
 
+def test_auto_picks_lane_groups_for_mid_size_scattered_matrices_in_both_formats(gpu, oracle):
+    """A mid-size matrix with scattered columns gets neither plan; AUTO then resolves to the lane-group kernel for CSR
+    (round 2) and for HLL (round 3: hll_lds was 12-27 % slower on every such stand-in of the reference's list) --
+    unless the rows are skewed, where lane groups of a fixed width lose."""
+    from _util import coo_from_csr
+    rng = np.random.default_rng(91)
+    M = N = 40_000
+    lens0 = np.minimum(rng.poisson(9, M), 14).astype(np.int64)
+    rows0 = np.repeat(np.arange(M), lens0)
+    cols0 = rng.integers(0, N, int(lens0.sum()))
+    order0 = np.lexsort((cols0, rows0))
+    rp = np.concatenate([[0], np.cumsum(lens0)]).astype(np.int32)
+    col, val = cols0[order0].astype(np.int32), rng.uniform(-1, 1, int(lens0.sum()))
+    x = rng.uniform(-1, 1, N)
+    y_ref = oracle.csr_serial(rp, col, val, x)
+    with sp.CsrDevice(M, N, rp, col, val) as dev:
+        info = dev.info()
+        assert info["local_blocks"] == 0 and info["tile_blocks"] == 0 and info["auto_variant"] == sp.CSR_SUBWAVE
+        assert_parity(dev.spmv(x, sp.CSR_AUTO), y_ref, rp, col, val, x, what="csr auto = subwave")
+        with sp.HllDevice.from_csr_device(dev) as h:
+            hi = h.info()
+            assert hi["local_blocks"] == 0 and hi["auto_variant"] == sp.HLL_SUBWAVE
+            assert_parity(h.spmv(x, sp.HLL_AUTO), y_ref, rp, col, val, x, what="hll auto = subwave")
+    # one hack with rows twenty times the mean: hll_lds keeps the slab
+    lens = np.diff(rp).astype(np.int64)
+    lens[5000:5032] = 400
+    rows = np.repeat(np.arange(M), lens)
+    cols2 = rng.integers(0, N, int(lens.sum()))
+    order = np.lexsort((cols2, rows))
+    rp2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    c2, v2 = cols2[order].astype(np.int32), rng.uniform(-1, 1, int(lens.sum()))
+    r, c, v = coo_from_csr(rp2, c2, v2)
+    with sp.HllDevice(sp.convert_to_hll(sp.PreMatrix.from_arrays(M, N, r, c, v))) as h:
+        assert h.info()["auto_variant"] == sp.HLL_LDS
+        assert_parity(h.spmv(x, sp.HLL_AUTO), oracle.csr_serial(rp2, c2, v2, x), rp2, c2, v2, x, what="hll auto = lds (skewed hack)")
+
+
 def test_small_matrix_with_scattered_rows_keeps_one_launch(gpu, oracle):
     """The same shape below 2^20 entries: no x-window plan with split rows (two more launches would cost more than the
     whole product); the gather kernel takes everything, and the blocks around the long rows hold few rows."""
@@ -1144,6 +1181,61 @@ def test_interior_and_boundary_blocks_emulated_ranks(gpu, oracle):
             d.close()
 
 
+def test_column_split_emulated_ranks(gpu, oracle):
+    """N4 overlap below block granularity (round 3): on a KKT-coupled cut every block of a rank also lists lines of the
+    coupling block, which another rank owns -- no interior BLOCKS -- but about half of a row's entries have their column
+    in the rank's own range.  spmv_hip_csr_split_columns splits the handle by column; part 0 must read nothing of x
+    outside the own range (the halo is NaN while it runs), part 0 then part 1 = the product of the oracle within 1e-10,
+    and twice the same bits."""
+    from sparsematrixvectormultiplication_amd import synth
+    rng = np.random.default_rng(65)
+    M, row_ptr, col, val = synth.kkt_like((24, 24, 25), 5)
+    x0 = rng.uniform(0.5, 1.0, M)
+    ref = oracle.csr_serial(row_ptr, col, val, x0)
+    bounds = sp.partition_rows(row_ptr, 4)
+    shares = []
+    for r in range(4):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        with sp.CsrDevice(M, M, row_ptr, col, val, row0=lo, row1=hi) as d:
+            blocks = d.split_interior()
+            counts = d.split_columns(lo, hi)
+            sl = slice(int(row_ptr[lo]), int(row_ptr[hi]))
+            inside = int(np.count_nonzero((col[sl] >= lo) & (col[sl] < hi)))
+            assert counts == {"own_entries": inside, "halo_entries": (sl.stop - sl.start) - inside}
+            shares.append((blocks["interior_entries"] / (sl.stop - sl.start), inside / (sl.stop - sl.start)))
+            x_own = np.full(M, np.nan)
+            x_own[lo:hi] = x0[lo:hi]                                          # the halo has not arrived
+            d.set_x(x_own)
+            sp.lib().spmv_hip_memset(d.y_ptr, 0xFF, M * 8)
+            d.run_split(0)
+            y_mid = d.get_y()[lo:hi].copy()
+            assert not np.any(np.isnan(y_mid))                                # part 0 wrote every row and read no halo
+            own_only = oracle.csr_serial(row_ptr, np.where((col >= lo) & (col < hi), col, 0).astype(np.int32),
+                                         np.where((col >= lo) & (col < hi), val, 0.0), x0)[lo:hi]
+            assert np.max(np.abs(y_mid - own_only) / np.maximum(np.abs(own_only), 1e-300)) <= 1e-10
+            d.set_x(x0)                                                       # ... now it has
+            d.run_split(1)
+            y_two = d.get_y()[lo:hi].copy()
+            assert np.max(np.abs(y_two - ref[lo:hi]) / np.maximum(np.abs(ref[lo:hi]), 1e-300)) <= 1e-10
+            d.run_split(0)
+            d.run_split(1)
+            assert d.get_y()[lo:hi].tobytes() == y_two.tobytes()              # a fixed order of the two partial sums
+            # the handle's one-launch product is untouched by the split
+            assert np.max(np.abs(d.spmv(x0, sp.CSR_STREAM)[lo:hi] - ref[lo:hi]) / np.abs(ref[lo:hi])) <= 1e-10
+    # the KKT cut: (almost) no interior blocks on the ranks that hold grid rows, but a large share of interior ENTRIES
+    assert max(b for b, _ in shares) < 0.2 and min(c for _, c in shares) > 0.35, shares
+    # a rank that owns everything has no halo entries: no sub-handles, run_split(0) is the whole product
+    rp2, c2, v2 = random_csr(rng, 3000, 3000, 5, 40, 0.0)
+    with sp.CsrDevice(3000, 3000, rp2, c2, v2) as whole:
+        assert whole.split_columns(0, 3000)["halo_entries"] == 0
+        xs = rng.uniform(-1, 1, 3000)
+        y_ref = whole.spmv(xs, sp.CSR_AUTO)
+        sp.lib().spmv_hip_memset(whole.y_ptr, 0xFF, 3000 * 8)
+        whole.run_split(0)
+        whole.run_split(1)
+        assert whole.get_y().tobytes() == y_ref.tobytes()
+
+
 def test_power_iteration_halo_single_rank_communicator(gpu):
     """The RCCL side at world size 1: setup (all-gather of the needs record), an exchange with no peers, the
     all-reduce of the norm; the halo loop then gives the plain loop's result bit for bit."""
@@ -1171,6 +1263,22 @@ def test_power_iteration_halo_single_rank_communicator(gpu):
                 dev.set_x(x0)
                 lam_serial, _ = dev.power_iterate_halo(4)
                 assert lam_serial == lam_plain and dev.get_x().tobytes() == x_plain.tobytes()
+            finally:
+                set_tuning("halo_overlap", 1)
+            # the loop over a column-split handle (what halo setup makes on a KKT-like cut at world size > 1; here made
+            # by hand, a world of one has no halo): two launches per product, overlapped or in order the same bits, and
+            # the plain loop's result within the tolerance (a row's two partial sums are added in another order)
+            assert dev.split_columns(n // 4, 3 * n // 4)["halo_entries"] > 0
+            dev.set_x(x0)
+            lam_split, _ = dev.power_iterate_halo(4)
+            x_split = dev.get_x()
+            assert abs(lam_split - lam_plain) <= 1e-10 * abs(lam_plain)
+            assert np.max(np.abs(x_split - x_plain) / np.maximum(np.abs(x_plain), 1e-300)) <= 1e-10
+            set_tuning("halo_overlap", 0)
+            try:
+                dev.set_x(x0)
+                lam_split_serial, _ = dev.power_iterate_halo(4)
+                assert lam_split_serial == lam_split and dev.get_x().tobytes() == x_split.tobytes()
             finally:
                 set_tuning("halo_overlap", 1)
         finally:

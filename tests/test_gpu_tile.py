@@ -36,9 +36,10 @@ class tuned:
             set_tuning(k, v)
 
     def __exit__(self, *exc):
-        defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1024, "tile_density": 4, "stream_kind": -1,
+        defaults = {"stream_tile": -1, "tile_rows": 0, "tile_lmax": 1536, "tile_density": 4, "stream_kind": -1,
                     "tile_balance": 1, "tile_long": 1, "tile_pack": 1, "stream_local": 1, "tile_places": 0,
-                    "tile_streams": 1, "tile_fit": 1, "tile_plan_on_device": 1, "place_tries": 12, "tile_min_pass": 256, "tile_mid": 1}
+                    "tile_streams": 1, "tile_fit": 1, "tile_plan_on_device": 1, "place_tries": 12, "tile_min_pass": 256, "tile_mid": 1,
+                    "tile_expand": -1}
         for k in self.kv:
             set_tuning(k, defaults[k])
 
@@ -87,6 +88,54 @@ def test_tile_kernel_gather_passes_uniform_columns(gpu, oracle, dtype, rows):
                 y0 = dev.spmv(x, sp.CSR_STREAM)
             scale = np.max(np.abs(y_ref))
             assert np.max(np.abs(y.astype(np.float64) - y0)) <= (1e-10 if dtype == np.float64 else 1e-5) * scale
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N", [2_000_003, 8192 * 5, 4097])
+def test_tile_kernel_expanded_x_gives_the_gather_passes_bits(gpu, oracle, dtype, N):
+    """Round 3: a plan with gather passes runs on an EXPANDED x -- tile_expand writes every entry's x value into its pass's
+    segment of a second vector x' (walking the entries by 32 KiB slice of x, the slice in LDS), and the packed kernel
+    runs over x' with every pass's segment as its window.  The same products in the same order: the bits of the gather
+    passes, which the same handle runs when "tile_expand" is 0 at launch.  N: a last slice of 3 values, whole slices,
+    one short slice."""
+    rng = np.random.default_rng(77)
+    M = 9001
+    lens = rng.poisson(14, M)
+    lens[::997] = 3000                                    # a few long rows: runs across lanes, wavefronts and passes
+    lens[5] = 0
+    rp, col, val = scattered(rng, M, N, 14, dtype=dtype, lens=lens)
+    x = rng.uniform(-1, 1, N).astype(dtype)
+    y_ref = reference(oracle, rp, col, val, x, dtype)
+    with tuned(stream_tile=1, tile_rows=1024, tile_expand=1, tile_lmax=4096, tile_density=0, tile_pack=0, stream_local=0):
+        with sp.CsrDevice(M, N, rp, col, val) as dev:
+            info = dev.info()
+            assert info["stream_kernel"] == 3 and info["tile_staged_entries"] == 0
+            assert info["tile_expanded_entries"] >= info["tile_entries"] == rp[-1]
+            y = check(dev, x, y_ref, rp, col, val, dtype, f"expanded N={N}")
+            set_tuning("tile_expand", 0)                  # the same handle, the gather passes
+            y_gather = check(dev, x, y_ref, rp, col, val, dtype, f"gather N={N}")
+            assert y.tobytes() == y_gather.tobytes()
+            set_tuning("tile_expand", 1)
+            # a foreign, misaligned x: the expansion copies 16-byte pieces -- such a launch takes the gather passes
+            L, item = sp.lib(), x.itemsize
+            buf, ybuf = C.c_void_p(), C.c_void_p()
+            assert L.spmv_hip_malloc(C.byref(buf), (N + 64) * item) == 0 and L.spmv_hip_malloc(C.byref(ybuf), M * item) == 0
+            try:
+                for shift in (item, 0):
+                    xp = C.c_void_p(buf.value + shift)
+                    assert L.spmv_hip_memcpy_h2d(xp, x.ctypes.data_as(C.c_void_p), N * item) == 0
+                    assert L.spmv_hip_memset(ybuf, 0xFF, M * item) == 0
+                    assert L.spmv_hip_csr_run_on(dev.h, sp.CSR_STREAM, xp, ybuf, None) == 0
+                    y2 = np.empty(M, dtype)
+                    assert L.spmv_hip_memcpy_d2h(y2.ctypes.data_as(C.c_void_p), ybuf, M * item) == 0
+                    assert y2.tobytes() == y.tobytes(), f"run_on shift={shift}"
+            finally:
+                L.spmv_hip_free(buf)
+                L.spmv_hip_free(ybuf)
+    # auto: a small plan is not expanded
+    with tuned(stream_tile=1, tile_rows=1024):
+        with sp.CsrDevice(M, N, rp, col, val) as dev:
+            assert dev.info()["tile_expanded_entries"] == 0
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -37,12 +37,15 @@ def test_hot_kernels_do_not_spill_and_keep_their_occupancy():
     # csr_tile<T, NT, 2048, 4, PACK, GA>: the GA (gather ahead) instantiations are an experiment that did not pay and is off
     # by default (profiles/r3_ab_gather_ahead.txt); the product's eight are the ones held to the budget
     all_tile = {k: v for k, v in kernels.items() if "csr_tile" in k}
-    tile = {k: v for k, v in all_tile.items() if re.search(r"csr_tileI[df]Lb[01]ELi2048ELi4ELb[01]ELb0EE", k)}
+    # (Li1 / Li2: the packed kernel with one or two staging trips, for the expanded plans)
+    tile = {k: v for k, v in all_tile.items() if re.search(r"csr_tileI[df]Lb[01]ELi2048ELi[124]ELb[01]ELb0EE", k)}
     # (the measurement-only STAMP instantiations of csr_stream_local are the ...ELb1EE ones)
     local = {k: v for k, v in kernels.items() if "csr_stream_local" in k and not k.split("csr_stream_localI")[1].startswith(
         ("dLb0ELi2048ELb1", "dLb1ELi2048ELb1"))}
-    assert len(tile) == 8 and len(all_tile) == 12 and len(local) >= 6, sorted(kernels)  # {fp64, fp32} x {nt} x {packed}; stages x {nt} x dtypes
-    for name, (scratch, vgprs) in {**tile, **local}.items():
+    assert len(tile) == 12 and len(all_tile) == 16 and len(local) >= 6, sorted(kernels)  # {fp64, fp32} x {nt} x {packed}; stages x {nt} x dtypes
+    expand = {k: v for k, v in kernels.items() if "tile_expand" in k}  # x into the passes' segments (expanded plans)
+    assert len(expand) == 2, sorted(kernels)
+    for name, (scratch, vgprs) in {**tile, **local, **expand}.items():
         assert scratch == 0, f"{name} spills {scratch} bytes of scratch ({vgprs} VGPRs)"
     for name, (_, vgprs) in tile.items():
         assert vgprs <= 128, f"{name}: {vgprs} VGPRs: two workgroups per CU no longer fit"

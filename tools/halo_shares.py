@@ -17,8 +17,8 @@ for name, gen in (("nlpkkt120-like 120x120x123", lambda: synth.kkt_like()),
     M, rp, col, val = gen()
     bounds = sp.partition_rows(rp, 8)
     print(f"== {name}: M={M} nnz={int(rp[-1])}, 8 nnz-balanced row blocks")
-    print("| rank | rows | x-window blocks | interior blocks | boundary blocks | interior entries | boundary entries | interior share | kernel interior us | boundary us | whole us |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| rank | rows | x-window blocks | interior blocks | boundary blocks | interior entries | boundary entries | interior share | kernel interior us | boundary us | whole us | column split: own entries | halo entries | own share | own us | halo us |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for r in range(8):
         lo, hi = int(bounds[r]), int(bounds[r + 1])
         with sp.CsrDevice(M, M, rp, col, val, lo, hi) as dev:
@@ -40,5 +40,11 @@ for name, gen in (("nlpkkt120-like 120x120x123", lambda: synth.kkt_like()),
             t_out = timed(lambda: dev.run_part(1))
             t_all = timed(lambda: dev.run(sp.CSR_STREAM))
             share = c["interior_entries"] / max(1, c["interior_entries"] + c["boundary_entries"])
+            # below block granularity (round 3): the handle split by column
+            cs = dev.split_columns(lo, hi)
+            t_own = timed(lambda: dev.run_split(0))
+            t_halo = timed(lambda: dev.run_split(1))
+            cshare = cs["own_entries"] / max(1, cs["own_entries"] + cs["halo_entries"])
             print(f"| {r} | {hi - lo} | {dev.info()['local_blocks']} | {c['interior_blocks']} | {c['boundary_blocks']} | "
-                  f"{c['interior_entries']} | {c['boundary_entries']} | {share:.3f} | {t_in:.1f} | {t_out:.1f} | {t_all:.1f} |", flush=True)
+                  f"{c['interior_entries']} | {c['boundary_entries']} | {share:.3f} | {t_in:.1f} | {t_out:.1f} | {t_all:.1f} | "
+                  f"{cs['own_entries']} | {cs['halo_entries']} | {cshare:.3f} | {t_own:.1f} | {t_halo:.1f} |", flush=True)

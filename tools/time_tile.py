@@ -63,6 +63,8 @@ for name in want:
     t = time.perf_counter()
     M, rp, col, val = CASES[name]()
     nnz = int(rp[-1])
+    if os.environ.get("TILE_F32"):
+        val = val.astype(np.float32)
     x = np.ones(M, dtype=val.dtype)
     print(f"== {name}: M={M} nnz={nnz} dtype={val.dtype} built in {time.perf_counter() - t:.1f}s", flush=True)
     set_tuning("stream_tile", 0)
@@ -84,7 +86,7 @@ for name in want:
             set_tuning("tile_items", int(os.environ.get("TILE_ITEMS", "1008")))
             set_tuning("tile_min_pass", int(os.environ.get("TILE_MIN_PASS", "256")))
             set_tuning("tile_pack", dn_pack)
-            set_tuning("tile_lmax", int(os.environ.get("TILE_LMAX", "1024")))
+            set_tuning("tile_lmax", int(os.environ.get("TILE_LMAX", "1536")))
             set_tuning("stream_tile", 1)
             set_tuning("tile_rows", tr)
             set_tuning("tile_density", dn)
@@ -98,7 +100,7 @@ for name in want:
                 for probe in [int(v) for v in os.environ.get("TILE_PROBE", "").split(",") if v]:  # EXPERIMENTAL=1 builds only
                     set_tuning("tile_probe", probe)
                     pm = dev.time(sp.CSR_STREAM, 2, 10, zero_y=False)
-                    print(f"      probe {probe} (1 loads, staging, barriers only; 2 no gathers; 4 no run sums; 8 one workgroup per CU): {pm.mean() * 1e3:8.1f} us", flush=True)
+                    print(f"      probe {probe} (1 loads, staging, barriers only -- expanded plans: + x' written in slice order; 2 no gathers; 4 no run sums; 8 one workgroup per CU): {pm.mean() * 1e3:8.1f} us", flush=True)
                     set_tuning("tile_probe", 0)
                 print(f"   tile pack={dn_pack} rows={tr:5d} density={dn:3d}: {ms.mean() * 1e3:8.1f} us  {info['algo_bytes'] / ms.mean() / 1e6:7.0f} GB/s  "
                       f"{info['algo_bytes'] / ms.mean() / 1e6 / 80:5.1f} %  blocks={info['tile_blocks']} passes={info['tile_passes']} "
