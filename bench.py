@@ -428,7 +428,20 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
         rooflines = [{"bound": "hbm", "achieved": round(info["algo_bytes"] / t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": round(info["algo_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
                       "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(info["algo_bytes"])}]
+        expanded = int(info.get("tile_expanded_entries", 0))
+        if expanded and kernel == "csr_tile":
+            # (round 3) the short rows' passes no longer gather: tile_expand writes every entry's x value into its pass's
+            # segment of x' and the packed kernel stages that segment -- what the product moves is its format's bytes
+            gathered = 0
+            rooflines.append({"bound": "hbm", "basis": "format bytes", "achieved": round(info["stream_bytes"] / t / 1e9, 1),
+                              "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(info["stream_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4),
+                              "format_bytes_per_launch": int(info["stream_bytes"]), "expanded_entry_slots": expanded,
+                              "note": "no gather passes left (expanded plan): every tier streams entries and x slices / "
+                                      "segments; format bytes = entries, descriptors, slabs, x' written and read, x and y once "
+                                      "(x slices staged out of L2 not counted)"})
         try:
+            if expanded and kernel == "csr_tile":
+                raise StopIteration
             peak = sp.gather_probe(4, 2 << 20, 16)
             rooflines.append({"bound": "l2_gather", "achieved": round(gathered / t / 1e9, 2), "peak": round(peak / 1e9, 2),
                               "unit": "G gathered values/s", "frac": round(gathered / t / peak, 4),
@@ -436,6 +449,8 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
                               "note": "achieved = values the product gathers (entries of passes not staged in LDS) / time of the "
                                       "WHOLE product, staged passes and the long rows' launch included; peak = 64-different-"
                                       "lines gathers from a 2 MiB table, 16 wavefronts per CU x 8 in flight, measured in this run"})
+        except StopIteration:
+            pass
         except Exception as exc:
             rooflines.append({"bound": "l2_gather", "error": str(exc)})
         return {"workload": "power-law 2^24 x 2^24 fp32 CSR (config 5 on one GPU; no reference counterpart for fp32)",
@@ -446,6 +461,8 @@ def side_measurement(sp, synth, which, steps, warmup, cpu_sweep=False):
                          "pct_of_8TBs": round(info["algo_bytes"] / (ms.mean() * 1e-3) / 1e9 / 80.0, 2),
                          "rows_in_split_row_kernels": info["tile_split_rows"],
                          "entries_in_tiles": info["tile_entries"], "entries_in_staged_passes": info["tile_staged_entries"],
+                         "entry_slots_on_expanded_x": expanded, "entries_in_middle_tier": info.get("tile_mid_entries", 0),
+                         "entries_in_long_rows_tier": info.get("tile_long_entries", 0),
                          "format_bytes": info["stream_bytes"]}}
     M, row_ptr, col, val = synth.fem_like()
     nnz = int(row_ptr[-1])

@@ -59,7 +59,11 @@ write = per_product("pmc_write", "WRITE_SIZE", products)
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 table = json.load(open(out_path)) if os.path.exists(out_path) else {}
 table = {k: v for k, v in table.items() if isinstance(v, dict)}  # round-1 entries carried no stamp
-hits = [k for k in fetch if k.split("(")[0].split("<")[0].strip().endswith(kernel.split("<")[0])]
+# a product of csr_tile is several kernels: the tiers' csr_tile launches, tile_expand ahead of an expanded plan, the slab
+# sums and the remainder behind them -- all of them move the product's bytes
+COMPANIONS = {"csr_tile": ("tile_expand", "tile_slab_finish", "tile_remainder", "csr_long_pieces", "csr_long_finish")}
+names = (kernel.split("<")[0],) + COMPANIONS.get(kernel.split("<")[0], ())
+hits = [k for k in fetch if k.split("(")[0].split("<")[0].strip().endswith(names)]
 if not hits:
     raise SystemExit(f"kernel {kernel} not found among {sorted(fetch)}")
 # a kernel may run as several instantiations per product (csr_tile: ordinary tiles without the packed decode + the
@@ -70,7 +74,7 @@ table[f"{kernel}|{workload}"] = {
     "bytes": int((2 * f + w) * 1024), "fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1),
     "source": tag, "kernel_src_sha": kernel_source_sha(kernel),
     "format_bytes": int(line["roofline"]["format_bytes_per_launch"]),
-    "blocks": int(line["config"]["workgroups"]), "instantiations": len(hits),
+    "blocks": int(line["config"]["workgroups"]), "instantiations": len(hits), "kernels": sorted({k.split("(")[0].split("<")[0].split("::")[-1].strip() for k in hits}),
     "kernel_ms_mean_unprofiled": line["roofline"]["kernel_ms_mean"]}
 print(f"{kernel}|{workload}: FETCH_SIZE={f:.0f} KiB WRITE_SIZE={w:.0f} KiB -> {(2 * f + w) * 1024 / 1e6:.1f} MB ({len(hits)} instantiation(s))")
 json.dump(table, open(out_path, "w"), indent=1, sort_keys=True)
