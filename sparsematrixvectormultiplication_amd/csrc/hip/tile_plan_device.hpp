@@ -524,21 +524,21 @@ __global__ __launch_bounds__(256) void expand_pass_of(int passes, const int4 *__
     const int4 d = pass[p];
     for (int i = threadIdx.x; i < ((d.y + 3) & ~3); i += 256) pass_of[d.x + i] = (unsigned)p;
 }
-// sort 1: key = first slot of the pass's region << 32 | slice of the entry's column (slots behind a pass's entries, and
-// slots no pass owns: all ones in the low word -- behind the pass's entries); payload = the slot.  Regions are disjoint
-// and cover every slot: a region occupies the same positions before and after the sort
+// sort 1: key = first slot of the pass's region << slice_bits | slice of the entry's column (slots behind a pass's entries,
+// and slots no pass owns: `slices`, one more than any slice -- behind the pass's entries); payload = the slot.  Regions are
+// disjoint and cover every slot: a region occupies the same positions before and after the sort
 __global__ __launch_bounds__(256) void expand_keys(size_t n, const int *__restrict__ tcol, const unsigned *__restrict__ pass_of,
-                                                   const int4 *__restrict__ pass, int slice_shift, unsigned slices,
+                                                   const int4 *__restrict__ pass, int slice_shift, unsigned slices, unsigned slice_bits,
                                                    unsigned long long *__restrict__ keys, unsigned *__restrict__ slot) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
         const unsigned p = pass_of[e];
-        unsigned lo = 0xffffffffu, region = (unsigned)e;  // (a slot no pass owns: a region of its own)
+        unsigned lo = slices, region = (unsigned)e;  // (a slot no pass owns: a region of its own)
         if (p != 0xffffffffu) {
             const int4 d = pass[p];
             region = (unsigned)d.x;
             if ((long long)e < (long long)d.x + d.y) lo = min((unsigned)tcol[e] >> slice_shift, slices - 1);
         }
-        keys[e] = ((unsigned long long)region << 32) | lo;
+        keys[e] = ((unsigned long long)region << slice_bits) | lo;
         slot[e] = (unsigned)e;
     }
 }
@@ -546,11 +546,11 @@ __global__ __launch_bounds__(256) void expand_keys(size_t n, const int *__restri
 // orders).  place[e] = q; the key of sort 2 = the slice (slots that are not entries: the last slice, expanded like
 // entries, read by nobody), payload q
 __global__ __launch_bounds__(256) void expand_places(size_t n, const unsigned long long *__restrict__ sorted, const unsigned *__restrict__ order1,
-                                                     unsigned slices, unsigned *__restrict__ place, unsigned *__restrict__ key2,
-                                                     unsigned *__restrict__ pos) {
+                                                     unsigned slices, unsigned slice_bits, unsigned *__restrict__ place,
+                                                     unsigned *__restrict__ key2, unsigned *__restrict__ pos) {
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
         place[order1[q]] = (unsigned)q;
-        key2[q] = min((unsigned)sorted[q], slices - 1);
+        key2[q] = min((unsigned)(sorted[q] & ((1ull << slice_bits) - 1)), slices - 1);
         pos[q] = (unsigned)q;
     }
 }
@@ -655,14 +655,16 @@ int tile_build_expansion(int N, const int *tcol, const unsigned short *tkey, siz
     if (e == hipSuccess) e = hipMemsetAsync(ex.words + n, 0, (size_t)kTileChunkMax * sizeof(int), s);
     if (bad(e, "allocation")) return -1;
     if (passes > 0) hipLaunchKernelGGL(expand_pass_of, dim3(passes), dim3(256), 0, s, passes, d_pass, pass_of);
-    hipLaunchKernelGGL(expand_keys, dim3(4096), dim3(256), 0, s, n, tcol, pass_of, d_pass, slice_shift, slices, keys_a, slot_a);
+    const unsigned slice_bits = bits_for((unsigned long long)slices);  // values 0 .. slices
+    const unsigned key_bits = slice_bits + bits_for((unsigned long long)n);
+    hipLaunchKernelGGL(expand_keys, dim3(4096), dim3(256), 0, s, n, tcol, pass_of, d_pass, slice_shift, slices, slice_bits, keys_a, slot_a);
     size_t tmp_bytes = 0;
     void *d_tmp = nullptr;
-    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, slot_a, order1, n, 0u, 64u, s);
+    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, slot_a, order1, n, 0u, key_bits, s);
     if (e == hipSuccess) e = tmp.alloc((char **)&d_tmp, tmp_bytes);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, keys_a, keys_b, slot_a, order1, n, 0u, 64u, s);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, keys_a, keys_b, slot_a, order1, n, 0u, key_bits, s);
     if (bad(e, "sort by (pass, slice)")) return -1;
-    hipLaunchKernelGGL(expand_places, dim3(4096), dim3(256), 0, s, n, keys_b, order1, slices, place, key2_a, pos_a);
+    hipLaunchKernelGGL(expand_places, dim3(4096), dim3(256), 0, s, n, keys_b, order1, slices, slice_bits, place, key2_a, pos_a);
     size_t tmp2_bytes = 0;
     void *d_tmp2 = nullptr;
     const unsigned end_bit = bits_for((unsigned long long)slices);

@@ -441,7 +441,7 @@ def test_tile_kernel_random_shapes(gpu, oracle):
     poisoned first and the launch repeated (bit-reproducible)."""
     import os
     rng = np.random.default_rng(int(os.environ.get("TILE_FUZZ_SEED", "20260")))  # (other seeds / more cases: by hand)
-    packed_seen = plain_seen = 0
+    packed_seen = plain_seen = expanded_seen = 0
     for case in range(int(os.environ.get("TILE_FUZZ_CASES", "64"))):
         dtype = np.float64 if case % 3 else np.float32
         M = int(rng.integers(1, 30_000))
@@ -466,12 +466,16 @@ def test_tile_kernel_random_shapes(gpu, oracle):
         places = int(rng.choice([0, 8, 16, 64]))
         if case % 8 == 7:
             rows_per_block = 0
+        # (tile_expand 1: plans with gather passes run on an expanded x whatever their size and type -- mixed plans with
+        # staged passes, empty blocks and single-entry passes included)
         with tuned(stream_tile=1, stream_local=0, tile_rows=rows_per_block, tile_pack=int(case % 6 != 5),
-                   tile_lmax=int(rng.choice([64, 1024])), tile_places=places, tile_streams=int(case % 11 != 10)):
+                   tile_lmax=int(rng.choice([64, 1024])), tile_places=places, tile_streams=int(case % 11 != 10),
+                   tile_expand=int(case % 2)):
             with sp.CsrDevice(M, N, rp, col, val) as dev:
                 info = dev.info()
                 if info["stream_kernel"] != 3:
                     continue  # (an empty matrix gets no plan)
+                expanded_seen += info["tile_expanded_entries"] > 0
                 if info["tile_entries"] and info["tile_staged_entries"] + info["tile_remainder_entries"] == info["tile_entries"]:
                     packed_seen += 1
                 else:
@@ -479,4 +483,4 @@ def test_tile_kernel_random_shapes(gpu, oracle):
                 check(dev, x, y_ref, rp, col, val, dtype,
                       f"case {case}: M={M} N={N} mean={mean} sigma={sigma} rows={rows_per_block} places={places} "
                       f"{np.dtype(dtype).name}")
-    assert packed_seen >= 8 and plain_seen >= 8, (packed_seen, plain_seen)
+    assert packed_seen >= 8 and plain_seen >= 8 and expanded_seen >= 4, (packed_seen, plain_seen, expanded_seen)
