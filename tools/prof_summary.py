@@ -8,14 +8,20 @@ from collections import defaultdict
 
 root = sys.argv[1]
 out = []
-for f in sorted(glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+def newest(pattern):
+    """the newest file only: a merged gpurun_out/ keeps earlier runs' files beside the last one's"""
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(os.path.join(root, "trace", "**", "*kernel_stats.csv")):
     out.append(f"== {os.path.relpath(f, root)}")
     out.append(open(f).read().strip())
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     acc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     out.append(f"== {os.path.basename(d)} (mean per dispatch; n dispatches)")
