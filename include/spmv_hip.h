@@ -165,6 +165,7 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
+ *                     "tile_mid_items" (0 = three rounds of the CUs) work items of the middle tier
  *                     "tile_expand" -1 | 0 | 1 (read at upload and at launch) a tile plan with gather passes runs on an
  *                         expanded x -- auto: from 2^22 entries on when under a tenth of them are staged; 0 never; 1 always
  *                     "tile_gather_ahead" 0 | 1 (read at launch) plans with gather passes send a pass's gathers out one pass

@@ -91,7 +91,8 @@ template <typename T, typename Build>
 bool build_long_tiles(int M, int N, const int *rp, const int *row_len, int chunk,
                       std::vector<unsigned char> &split, TilePlan<T> &plan, std::vector<int> &rows,
                       std::vector<int4> &work, std::vector<int> &item_first, bool &packed, Build build,
-                      int len_lo = 0, int len_hi = (1 << 21) - 1, int kPosBits = 21, int kRowsPerBlock = 2048) {
+                      int len_lo = 0, int len_hi = (1 << 21) - 1, int kPosBits = 21, int kRowsPerBlock = 2048, int items = 0) {
+    if (items <= 0) items = g_tile_items;
     rows.clear();
     long long entries = 0;
     for (int r = 0; r < M; ++r)
@@ -115,7 +116,7 @@ bool build_long_tiles(int M, int N, const int *rp, const int *row_len, int chunk
     for (int r : rows) split[(size_t)r] = 0;
     // work items: ~tile_items (1008: two rounds of the 512 places) of them over all blocks, at least 4 passes each
     const long long passes = (long long)plan.pass_desc.size();
-    const int per_item = (int)std::max<long long>(4, (passes + g_tile_items - 1) / g_tile_items);
+    const int per_item = (int)std::max<long long>(4, (passes + items - 1) / items);
     work.clear();
     item_first.assign(1, 0);
     for (int b = 0; b < plan.num_blocks; ++b) {
@@ -356,7 +357,9 @@ void tile_plan_all(int Ml, int N, const int *row_begin, const int *row_len, cons
                 }
                 return build_at(rows, begin_h, len_h, d_begin, d_len, rpb, lmax, pos_bits, pack, 0, 0, plan, tb.mtiles_dev);
             },
-            mid_lo, g_tile_lmax, 17, scattered_rows_max);
+            // (its blocks fill a CU's LDS: one workgroup per CU, so whole rounds of the CUs -- three of them: config 5
+            // 1008 / 954 / 898 / 918 / 943 / 996 us at 256 / 512 / 768 / 1008 / 1280 / 2016 items, profiles/r3_sweep_mid_items.txt)
+            mid_lo, g_tile_lmax, 17, scattered_rows_max, g_tile_mid_items ? g_tile_mid_items : 3 * std::max(g_num_cus, 1));
     if (want_mid && tb.have_tiles && (!tb.have_mid_tiles || !tb.mt_packed)) {
         // the tier did not come about (its passes would average fewer than 256 entries, or its build failed): the plan
         // without one, from the start -- the ordinary tiles then take the rows up to tile_lmax again

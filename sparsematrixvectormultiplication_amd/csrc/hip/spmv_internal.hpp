@@ -55,6 +55,7 @@ constexpr long long kSplitMinEntries = 1LL << 20;  // entries from which rows ma
 constexpr long long kTileMinRows = 800000;  // (auto) rows from which a handle without an x-window plan gets a tile plan
 extern int g_tile_min_pass;   // windows of a packed plan with fewer entries than this (and sparser than 1 per 16 columns) go to the remainder; 0: none
 extern int g_tile_places;     // 0: the chip's (2 or 1 workgroups per CU) | the number of workgroup places the streams / the block count are made for
+extern int g_tile_mid_items;  // work items of the middle tier (0: three rounds of the CUs)
 extern int g_tile_items;      // work items the long rows' passes are dealt out to (about)
 extern int g_tile_streams;    // 1: one csr_tile workgroup per place of the chip walks several row blocks back to back
 extern int g_tile_fit;        // 1: (auto rows) the number of row blocks is fitted to whole rounds of the chip's workgroup places
