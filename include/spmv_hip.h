@@ -167,7 +167,8 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
  *                     "tile_mid_items" (0 = three rounds of the CUs) work items of the middle tier
  *                     "tile_expand" -1 | 0 | 1 (read at upload and at launch) a tile plan with gather passes runs on an
- *                         expanded x -- auto: from 2^22 entries on when under a tenth of them are staged; 0 never; 1 always
+ *                         expanded x -- auto: from 2^22 entries on when under a tenth of them are staged, fp32 always, fp64
+ *                         when x is beyond 100 MB; 0 never; 1 always
  *                     "tile_gather_ahead" 0 | 1 (read at launch) plans with gather passes send a pass's gathers out one pass
  *                     early (twice as many in flight per CU) -- measured to buy nothing (1113 vs 1108 us on config 5, 514.9 vs
  *                     514.8 on uniformly random columns: profiles/r3_ab_gather_ahead.txt), hence off;

@@ -529,12 +529,14 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
     // tile_expand walks the entries slice by slice of x and writes every entry's value into its pass's segment of x',
     // which csr_tile<.., PACK> stages as that pass's window (tile_kernels.hpp).  The same products in the same order:
     // the same bits as the gather passes.
-    // auto: fp32 plans from 2^22 entries on with fewer than a tenth of them in staged passes -- an fp64 gather brings twice
-    // the bytes per line and the expansion moves twice the bytes per entry: uniformly random columns, 4 M rows x 20, fp64
-    // 519 us with gather passes, 665 us expanded; config 5's short rows (fp32) 491 -> 405 us (profiles/r3_ab_expand.txt)
+    // auto: plans from 2^22 entries on with fewer than a tenth of them in staged passes -- fp32 always (uniformly random
+    // columns, 2 M x 10 ... 16 M x 8: -17 ... -37 %; config 5's short rows 491 -> 141 + 180 us), fp64 when x is beyond
+    // 100 MB: an fp64 gather brings twice the bytes per line and the expansion moves twice the bytes per entry -- 4 M x
+    // 20: 518 -> 539 us, 12 M x 4: 462 -> 454, 16 M x 8: 1095 -> 939 (profiles/r3_ab_expand.txt)
     // ("tile_expand" 0: never, 1: always)
+    const bool expand_pays = sizeof(T) == 4 || (long long)m->N * (long long)sizeof(T) >= (100LL << 20);
     if (!rc && tb.have_tiles && !tb.packed && m->tcol && m->tile_padded > 0 &&
-        (g_tile_expand > 0 || (g_tile_expand < 0 && sizeof(T) == 4 && m->tile_entries >= (1 << 22) &&
+        (g_tile_expand > 0 || (g_tile_expand < 0 && expand_pays && m->tile_entries >= (1 << 22) &&
                                m->tile_staged * 10 <= m->tile_entries))) {
         const size_t slots = (size_t)m->tile_padded;
         m->expansion = new (std::nothrow) TileExpansion();
@@ -546,8 +548,8 @@ int tile_upload_all(spmv_csr_dev *m, const TileBuild<T> &tb) {
         hipError_t e = hipMalloc(&m->xe, xe_bytes);
         if (e == hipSuccess) e = hipMemsetAsync(m->xe, 0, xe_bytes, g_stream);
         if (e != hipSuccess) return fail("hipMalloc(expanded x) failed: %s", hipGetErrorString(e));
-        m->device_bytes += xe_bytes + (slots + 64) * 6 + (slots + kTileChunkMax) * 4 + tb.tiles.spass.size() * 16 +
-                           (size_t)m->expansion->chunks * 16;
+        m->device_bytes += xe_bytes + (slots + 64) * 2 + (slots + kTileChunkMax) * 4 + tb.tiles.spass.size() * 16 +
+                           (size_t)m->expansion->chunks * 24 + (m->expansion->runs + m->expansion->groups) * 4;
     }
     if (!rc && tb.have_long_tiles) upload_tier(tb.ltiles, tb.ltiles_dev.get(), tb.lt_rows, tb.lt_work, tb.lt_item_first, tb.lt_packed, m->lt);
     if (!rc && tb.have_mid_tiles) upload_tier(tb.mtiles, tb.mtiles_dev.get(), tb.mt_rows, tb.mt_work, tb.mt_item_first, tb.mt_packed, m->mt);
@@ -1767,11 +1769,12 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
                             4LL * m->tile_blocks +
                             std::max<long long>(0, m->nz - m->tile_entries - m->tile_rem_entries - m->lt.entries - m->mt.entries) * (vb + 4) +
                             m->tile_rem_entries * (vb + 4) + 16LL * m->tile_num_pieces + vb * m->M_local + vb * m->N;
-        // an expanded plan: tile_expand reads 2 + 4 bytes per entry and writes its x value, csr_tile reads that value as
-        // its window and a packed column word where it read column and key; every chunk copies its 32 KiB slice of x
-        // (out of L2 mostly)
+        // an expanded plan: tile_expand reads 2 bytes per entry (+ 4 per run and per 64 entries) and writes its x value,
+        // csr_tile reads that value as its window and a packed column word where it read column and key; every chunk
+        // copies its 32 KiB slice of x (out of L2 mostly)
         if (m->xe && m->expansion)
-            out->stream_bytes += (long long)m->expansion->entries * (2 * vb + 4) + 16LL * m->expansion->chunks;
+            out->stream_bytes += (long long)m->expansion->entries * (2 * vb) + 24LL * m->expansion->chunks +
+                                 4LL * (long long)(m->expansion->runs + m->expansion->groups);
         for (const spmv_csr_dev::long_tiles *tier : {&m->lt, &m->mt})  // entries, descriptors, slabs written and read
             out->stream_bytes += tier->padded * (vb + 6) - (tier->packed ? 2 : 0) * tier->staged + 16LL * tier->passes +
                                  2 * vb * (long long)tier->items * tier->rows_per_block;
@@ -1894,7 +1897,7 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     const bool expanded = m->xe && m->expansion && m->expansion->chunks > 0 && stage_ok && g_tile_expand != 0;
                     if (expanded) {
                         hipLaunchKernelGGL((tile_expand<T>), dim3(m->expansion->chunks), dim3(kExpandBlock), 0, s, m->N, g_tile_probe,
-                                           m->expansion->chunk, m->expansion->lcol, m->expansion->dest, x, (T *)m->xe);
+                                           m->expansion->chunk, m->expansion->chunk_runs, m->expansion->lcol, m->expansion->group_run, m->expansion->delta, x, (T *)m->xe);
                         // (a pass's window is its own segment: 2048 values at most, one staging trip in fp32, two in fp64)
                         constexpr int kXpTrips = 2048 * (int)sizeof(T) / kTileTripBytes;
                         const size_t xlds = std::max((size_t)m->tile_lds_min, (size_t)kTileSlotBytes + (size_t)m->tile_rows * sizeof(T) +

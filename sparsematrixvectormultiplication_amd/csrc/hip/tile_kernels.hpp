@@ -540,25 +540,35 @@ __global__ __launch_bounds__(kTileBlock, 4) void csr_tile(int num_blocks, int ro
 // LDS with coalesced loads, looks the columns up there, and writes the values to their segments -- the entries of one
 // (slice, pass) lie together in both orders, so the writes are runs, not single values.  The products and the order in
 // which a row's are added are those of the gather passes: the same bits.
-// x'[dest[k]] = x[slice * W + lcol[k]];  chunk = {slice, first k, entries, 0}: at most kExpandChunk entries of one slice.
-// (dest per entry is 4 of the kernel's 10 bytes per entry, and consecutive entries mostly have consecutive places: a
-// variant that stored one offset per RUN of such entries -- a start bit in lcol, the run numbered per wavefront with a
-// ballot -- read 6 bytes per entry and was SLOWER, 252 us against 189 on config 5's 63 M short-row entries: the offset
-// is a second, dependent trip to memory per entry.  With the places streamed in order the kernel runs at 108 us.)
+// Entry k (slice order) goes to x'[k + delta[r]], r = the RUN it belongs to -- consecutive entries whose places in x'
+// are consecutive too (the entries of one (slice, pass), or several that happen to touch): bit 15 of lcol marks a run's
+// first entry, group_run holds the run of every 64th entry of a chunk, and a wavefront numbers its lanes' runs with one
+// ballot.  The chunk's offsets (its first kExpandRunsLds runs) and group numbers are copied to LDS beside the slice:
+// 2 bytes read and one value written per entry: 141 us on config 5's 63 M short-row entries.  (A place per entry is 4
+// bytes more: 189 us; the offsets fetched from memory per entry -- a second, dependent trip -- 252 us; with the places
+// streamed in order, no offsets at all, 108 us.)
+// chunk = {slice, first k, entries, first group}; chunk_runs = {first run, runs}.
 constexpr int kExpandBlock = 512;
 constexpr int kExpandChunk = 16384;
+constexpr int kExpandRunsLds = 1024;
+constexpr unsigned kExpandRunStart = 0x8000u;
 template <typename T>
 constexpr int tile_slice_cols() {
     return kTileTrips * kTileTripBytes / (int)sizeof(T);
 }
 template <typename T>
-__global__ __launch_bounds__(kExpandBlock) void tile_expand(int N, int probe, const int4 *__restrict__ chunk,
-                                                            const unsigned short *__restrict__ lcol, const unsigned *__restrict__ dest,
-                                                            const T *__restrict__ x, T *__restrict__ xe) {
+__global__ __launch_bounds__(kExpandBlock) void tile_expand(int N, int probe, const int4 *__restrict__ chunk, const int2 *__restrict__ chunk_runs,
+                                                            const unsigned short *__restrict__ lcol, const unsigned *__restrict__ group_run,
+                                                            const unsigned *__restrict__ delta, const T *__restrict__ x,
+                                                            T *__restrict__ xe) {
     constexpr int W = tile_slice_cols<T>(), kPer = 16 / (int)sizeof(T);
+    static_assert(W <= (int)kExpandRunStart, "a column inside its slice leaves bit 15 free");
     __shared__ __attribute__((aligned(16))) T xs[W];
+    __shared__ unsigned dl[kExpandRunsLds];
+    __shared__ unsigned gl[kExpandChunk / 64];
     const int4 c = chunk[blockIdx.x];
-    const int t = threadIdx.x;
+    const int2 cr = chunk_runs[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63;
     const long long base = (long long)c.x * W;
     const int wlen = (int)min((long long)W, (long long)N - base);
     const int whole = wlen / kPer * kPer;
@@ -566,25 +576,32 @@ __global__ __launch_bounds__(kExpandBlock) void tile_expand(int N, int probe, co
     const v4u *src = reinterpret_cast<const v4u *>(x + base);
     for (int j = t * kPer; j < whole; j += kExpandBlock * kPer) *reinterpret_cast<v4u *>(xs + j) = src[j / kPer];
     if (t < wlen - whole) xs[whole + t] = x[base + whole + t];
+    const int n = c.z;
+    for (int j = t; j < min(cr.y, kExpandRunsLds); j += kExpandBlock) dl[j] = delta[cr.x + j];
+    for (int j = t; j < (n + 63) / 64; j += kExpandBlock) gl[j] = group_run[c.w + j] - (unsigned)cr.x;  // the run inside the chunk
     __syncthreads();
     const unsigned short *lc = lcol + c.y;
-    const unsigned *de = dest + c.y;
-    const int n = c.z;
+    const unsigned long long upto = (2ull << lane) - 1;  // lanes 0 .. lane
     constexpr int U = 8;  // loads of U trips in flight before the first store
-    for (int i0 = 0; i0 < n; i0 += U * kExpandBlock) {
-        unsigned d[U];
-        int l[U];
+    for (int i0 = 0; i0 < n; i0 += U * kExpandBlock) {  // wave-uniform
+        unsigned raw[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * kExpandBlock + t;
-            l[u] = i < n ? (int)stream_load<true>(lc + i) : 0;
-            // (probe, measurement only: bit 0 -- no dest read, the values go out in slice order, as a stream)
-            d[u] = (probe & 1) ? (unsigned)(c.y + i) : i < n ? stream_load<true>(de + i) : 0u;
+            raw[u] = i < n ? (unsigned)stream_load<true>(lc + i) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * kExpandBlock + t;
-            if (i < n) xe[d[u]] = xs[l[u]];
+            const bool in = i < n;
+            // the runs that begin in lanes 1 .. lane come on top of the run the group's first entry belongs to
+            const unsigned long long starts = __ballot(in && (raw[u] & kExpandRunStart)) & ~1ull;
+            if (in) {
+                const unsigned r = gl[i >> 6] + (unsigned)__popcll(starts & upto);
+                // (probe, measurement only: bit 0 -- the values go out in slice order, as a stream)
+                const unsigned dv = (probe & 1) ? 0u : r < (unsigned)kExpandRunsLds ? dl[r] : delta[(unsigned)cr.x + r];
+                xe[(unsigned)(c.y + i) + dv] = xs[raw[u] & (kExpandRunStart - 1)];
+            }
         }
     }
 }

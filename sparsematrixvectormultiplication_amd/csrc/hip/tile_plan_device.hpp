@@ -569,10 +569,33 @@ __global__ __launch_bounds__(256) void expand_starts(size_t n, const unsigned *_
 // lcol[k] = the column of the entry that lives at x'[dest[k]], inside its slice
 __global__ __launch_bounds__(256) void expand_lcol(size_t n, const unsigned *__restrict__ slice_sorted, const unsigned *__restrict__ dest,
                                                    const unsigned *__restrict__ order1, const int *__restrict__ tcol, int slice_shift,
-                                                   unsigned short *__restrict__ lcol) {
+                                                   const unsigned *__restrict__ run_start, unsigned short *__restrict__ lcol) {
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
         const long long l = (long long)(unsigned)tcol[order1[dest[k]]] - ((long long)slice_sorted[k] << slice_shift);
-        lcol[k] = (unsigned short)max(0ll, min(l, (1ll << slice_shift) - 1));
+        lcol[k] = (unsigned short)(max(0ll, min(l, (1ll << slice_shift) - 1)) | (run_start[k] ? kExpandRunStart : 0u));
+    }
+}
+// a RUN: consecutive entries of the slice order whose places in x' are consecutive as well (and in one slice)
+__global__ __launch_bounds__(256) void expand_run_starts(size_t n, const unsigned *__restrict__ slice_sorted, const unsigned *__restrict__ dest,
+                                                         unsigned *__restrict__ run_start) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256)
+        run_start[k] = k == 0 || dest[k] != dest[k - 1] + 1 || slice_sorted[k] != slice_sorted[k - 1];
+}
+// delta[r] = place - k for the entries of run r (runs_upto[k] = runs that have begun up to and including k)
+__global__ __launch_bounds__(256) void expand_run_delta(size_t n, const unsigned *__restrict__ run_start, const unsigned *__restrict__ runs_upto,
+                                                        const unsigned *__restrict__ dest, unsigned *__restrict__ delta) {
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256)
+        if (run_start[k]) delta[runs_upto[k] - 1] = dest[k] - (unsigned)k;
+}
+// group_run[chunk.w + j] = the run of the chunk's entry 64 j; chunk_runs = {the chunk's first run, its runs}
+__global__ __launch_bounds__(256) void expand_groups(int chunks, const int4 *__restrict__ chunk, const unsigned *__restrict__ runs_upto,
+                                                     unsigned *__restrict__ group_run, int2 *__restrict__ chunk_runs) {
+    if ((int)blockIdx.x >= chunks) return;
+    const int4 c = chunk[blockIdx.x];
+    for (int j = threadIdx.x; j < (c.z + 63) / 64; j += 256) group_run[c.w + j] = runs_upto[(size_t)c.y + 64 * (size_t)j] - 1;
+    if (threadIdx.x == 0) {
+        const unsigned r0 = runs_upto[(size_t)c.y] - 1, r1 = runs_upto[(size_t)c.y + (size_t)c.z - 1] - 1;
+        chunk_runs[blockIdx.x] = make_int2((int)r0, (int)(r1 - r0 + 1));
     }
 }
 // the packed column word of slot e: head << 31 | local row << 14 | place in the pass's segment of x'
@@ -602,16 +625,21 @@ __global__ __launch_bounds__(256) void expand_pass_desc(int passes, const int4 *
 
 // what tile_expand walks and what csr_tile<.., PACK> runs on, freed with the owner
 struct TileExpansion {
-    unsigned short *lcol = nullptr;  // [slots + pad] column inside the slice, slice order
-    unsigned *dest = nullptr;        // [slots + pad] the entry's place in x'
-    int4 *chunk = nullptr;           // [chunks] {slice, first, entries, 0}
+    unsigned short *lcol = nullptr;  // [slots + pad] column inside the slice | run start << 15, slice order
+    unsigned *delta = nullptr;       // [runs] place in x' - position in slice order, per run
+    unsigned *group_run = nullptr;   // [groups] the run of every 64th entry of a chunk
+    int4 *chunk = nullptr;           // [chunks] {slice, first, entries, first group}
+    int2 *chunk_runs = nullptr;      // [chunks] {first run, runs}
+    size_t runs = 0, groups = 0;
     int *words = nullptr;            // [slots + kTileChunkMax] packed column words, the plan's entry order
     int4 *pass = nullptr;            // [passes] the plan's descriptors with the pass's segment of x' as window
     int chunks = 0;
     size_t entries = 0;
     ~TileExpansion() {
         (void)hipFree(lcol);
-        (void)hipFree(dest);
+        (void)hipFree(delta);
+        (void)hipFree(group_run);
+        (void)hipFree(chunk_runs);
         (void)hipFree(chunk);
         (void)hipFree(words);
         (void)hipFree(pass);
@@ -636,7 +664,7 @@ int tile_build_expansion(int N, const int *tcol, const unsigned short *tkey, siz
         return true;
     };
     unsigned long long *keys_a, *keys_b;
-    unsigned *slot_a, *order1, *pass_of, *place, *key2_a, *key2_b, *pos_a, *first;
+    unsigned *slot_a, *order1, *pass_of, *place, *key2_a, *key2_b, *pos_a, *first, *dest, *run_start, *runs_upto;
     hipError_t e = tmp.alloc(&keys_a, n);
     if (e == hipSuccess) e = tmp.alloc(&keys_b, n);
     if (e == hipSuccess) e = tmp.alloc(&slot_a, n);
@@ -647,7 +675,9 @@ int tile_build_expansion(int N, const int *tcol, const unsigned short *tkey, siz
     if (e == hipSuccess) e = tmp.alloc(&key2_b, n);
     if (e == hipSuccess) e = tmp.alloc(&pos_a, n);
     if (e == hipSuccess) e = tmp.alloc(&first, (size_t)slices + 1);
-    if (e == hipSuccess) e = hipMalloc((void **)&ex.dest, (n + 64) * sizeof(unsigned));
+    if (e == hipSuccess) e = tmp.alloc(&dest, n);
+    if (e == hipSuccess) e = tmp.alloc(&run_start, n);
+    if (e == hipSuccess) e = tmp.alloc(&runs_upto, n);
     if (e == hipSuccess) e = hipMalloc((void **)&ex.lcol, (n + 64) * sizeof(unsigned short));
     if (e == hipSuccess) e = hipMalloc((void **)&ex.words, (n + kTileChunkMax) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&ex.pass, (size_t)std::max(passes, 1) * sizeof(int4));
@@ -668,31 +698,55 @@ int tile_build_expansion(int N, const int *tcol, const unsigned short *tkey, siz
     size_t tmp2_bytes = 0;
     void *d_tmp2 = nullptr;
     const unsigned end_bit = bits_for((unsigned long long)slices);
-    e = rocprim::radix_sort_pairs(nullptr, tmp2_bytes, key2_a, key2_b, pos_a, ex.dest, n, 0u, end_bit, s);
+    e = rocprim::radix_sort_pairs(nullptr, tmp2_bytes, key2_a, key2_b, pos_a, dest, n, 0u, end_bit, s);
     if (e == hipSuccess) e = tmp.alloc((char **)&d_tmp2, tmp2_bytes);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp2, tmp2_bytes, key2_a, key2_b, pos_a, ex.dest, n, 0u, end_bit, s);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp2, tmp2_bytes, key2_a, key2_b, pos_a, dest, n, 0u, end_bit, s);
     if (bad(e, "sort by slice")) return -1;
     hipLaunchKernelGGL(expand_starts, dim3((slices + 1 + 255) / 256), dim3(256), 0, s, n, key2_b, slices, first);
-    hipLaunchKernelGGL(expand_lcol, dim3(4096), dim3(256), 0, s, n, key2_b, ex.dest, order1, tcol, slice_shift, ex.lcol);
+    hipLaunchKernelGGL(expand_run_starts, dim3(4096), dim3(256), 0, s, n, key2_b, dest, run_start);
+    size_t tmp3_bytes = 0;
+    void *d_tmp3 = nullptr;
+    e = rocprim::inclusive_scan(nullptr, tmp3_bytes, run_start, runs_upto, n, rocprim::plus<unsigned>(), s);
+    if (e == hipSuccess) e = tmp.alloc((char **)&d_tmp3, tmp3_bytes);
+    if (e == hipSuccess) e = rocprim::inclusive_scan(d_tmp3, tmp3_bytes, run_start, runs_upto, n, rocprim::plus<unsigned>(), s);
+    if (bad(e, "numbering the runs")) return -1;
+    hipLaunchKernelGGL(expand_lcol, dim3(4096), dim3(256), 0, s, n, key2_b, dest, order1, tcol, slice_shift, run_start, ex.lcol);
     hipLaunchKernelGGL(expand_words, dim3(4096), dim3(256), 0, s, n, tkey, place, pass_of, d_pass, ex.words);
     if (passes > 0) hipLaunchKernelGGL(expand_pass_desc, dim3((passes + 255) / 256), dim3(256), 0, s, passes, d_pass, ex.pass);
     std::vector<unsigned> h_first((size_t)slices + 1);
+    unsigned runs = 0;
     e = hipMemcpyAsync(h_first.data(), first, h_first.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(&runs, runs_upto + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (bad(e, "keys, sorts, words")) return -1;
-    trace.mark("keys, two sorts, slice columns, packed words");
+    trace.mark("keys, two sorts, runs, slice columns, packed words");
     std::vector<int4> chunks;
+    size_t groups = 0;
     for (unsigned c = 0; c < slices; ++c)
-        for (unsigned k = h_first[c]; k < h_first[(size_t)c + 1]; k += (unsigned)kExpandChunk)
-            chunks.push_back(make_int4((int)c, (int)k, (int)std::min<unsigned>((unsigned)kExpandChunk, h_first[(size_t)c + 1] - k), 0));
+        for (unsigned k = h_first[c]; k < h_first[(size_t)c + 1]; k += (unsigned)kExpandChunk) {
+            const unsigned cnt = std::min<unsigned>((unsigned)kExpandChunk, h_first[(size_t)c + 1] - k);
+            chunks.push_back(make_int4((int)c, (int)k, (int)cnt, (int)groups));
+            groups += (cnt + 63) / 64;
+        }
     e = hipMalloc((void **)&ex.chunk, std::max<size_t>(1, chunks.size()) * sizeof(int4));
+    if (e == hipSuccess) e = hipMalloc((void **)&ex.chunk_runs, std::max<size_t>(1, chunks.size()) * sizeof(int2));
+    if (e == hipSuccess) e = hipMalloc((void **)&ex.delta, std::max<size_t>(1, runs) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&ex.group_run, std::max<size_t>(1, groups) * sizeof(unsigned));
     if (e == hipSuccess && !chunks.empty())
         e = hipMemcpyAsync(ex.chunk, chunks.data(), chunks.size() * sizeof(int4), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (bad(e, "chunks")) return -1;
+    hipLaunchKernelGGL(expand_run_delta, dim3(4096), dim3(256), 0, s, n, run_start, runs_upto, dest, ex.delta);
+    if (!chunks.empty())
+        hipLaunchKernelGGL(expand_groups, dim3((unsigned)chunks.size()), dim3(256), 0, s, (int)chunks.size(), ex.chunk, runs_upto,
+                           ex.group_run, ex.chunk_runs);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (bad(e, "runs, groups")) return -1;
     ex.chunks = (int)chunks.size();
     ex.entries = n;
+    ex.runs = runs;
+    ex.groups = groups;
     return 1;
 }
 
