@@ -110,6 +110,9 @@ typedef struct {
     unsigned long long val_address; /* where the value array lies now (placement record of a bench line) */
     long long tile_expanded_entries; /* CSR: entry slots of a tile plan with gather passes that run on an expanded x (tile_expand
                                         writes every entry's x value in entry order, csr_tile streams it: "tile_expand") */
+    long long pattern_slots; /* CSR: slots held by the pattern tables of an x-window plan (0: the kernel reads the 16-bit slot of
+                                every entry) -- where most rows of a block are their predecessor shifted by a constant the
+                                kernel rebuilds the slots from one table per block and 4 bytes per row ("local_patterns") */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -165,6 +168,9 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     many workgroups the streams and the block count are made for (tests); "tile_items" (1008) work items the long rows' passes are dealt out to;
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
+ *                     "local_patterns" -1 | 0 | 1 (read at upload and at launch) x-window plans: the kernel rebuilds a block's
+ *                         slots from a pattern table instead of reading them -- auto: where the tables hold at most a
+ *                         quarter of the slots (stencil-like matrices); 0 never; 1 always
  *                     "tile_mid_items" (0 = three rounds of the CUs) work items of the middle tier
  *                     "tile_expand" -1 | 0 | 1 (read at upload and at launch) a tile plan with gather passes runs on an
  *                         expanded x -- auto: from 2^22 entries on when under a tenth of them are staged, fp32 always, fp64

@@ -57,7 +57,8 @@ class DevInfo(C.Structure):
                 ("tile_staged_cols", C.c_longlong), ("tile_remainder_entries", C.c_longlong),
                 ("tile_mid_rows", C.c_int), ("tile_mid_items", C.c_int), ("tile_mid_entries", C.c_longlong),
                 ("place_tries", C.c_int), ("place_first_us", C.c_float), ("place_best_us", C.c_float),
-                ("val_address", C.c_ulonglong), ("tile_expanded_entries", C.c_longlong)]
+                ("val_address", C.c_ulonglong), ("tile_expanded_entries", C.c_longlong),
+                ("pattern_slots", C.c_longlong)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

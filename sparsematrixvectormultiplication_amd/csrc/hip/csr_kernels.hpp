@@ -411,7 +411,7 @@ template <typename T, bool NT, int CAP, int ROUNDS>
 __device__ __forceinline__ void local_stage_full(T *stage, const int *__restrict__ my_lines, int last_line,
                                                  const unsigned short *__restrict__ lcol,
                                                  const T *__restrict__ val, const T *__restrict__ x,
-                                                 int e_first) {
+                                                 int e_first, bool no_slots = false) {
     using V2 = typename vec2<T>::type;
     constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
     const int t = threadIdx.x;
@@ -428,7 +428,9 @@ __device__ __forceinline__ void local_stage_full(T *stage, const int *__restrict
     V2 v[kUnits];
 #pragma unroll
     for (int u = 0; u < kUnits; ++u) {
-        c[u] = stream_load<NT>(reinterpret_cast<const unsigned *>(lcol + e_first + u * kUnit));
+        // (no_slots, measurement only -- the STAMP instantiation's probe: the slot stream is not read at all; what the
+        // kernel would cost if a block's slots came from a per-block pattern instead of a 16-bit word per entry)
+        c[u] = no_slots ? (unsigned)(t & 15) * 0x10001u : stream_load<NT>(reinterpret_cast<const unsigned *>(lcol + e_first + u * kUnit));
         v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
     }
     // keep the HBM stream ahead of the wait for the list (the scheduler would otherwise sink
@@ -454,9 +456,127 @@ __device__ __forceinline__ void local_stage_full(T *stage, const int *__restrict
     for (int u = 0; u < kUnits; ++u) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = v[u];
 }
 
+// ---- slot PATTERNS (round 3).  The kernel is bound by its loads in flight, not by its bytes (12-bit slots: 4.6 % fewer
+// bytes, no time gained; the slot stream not read at all: 181 -> 145 us on the nlpkkt-like matrix).  And the slot stream
+// is redundant where the matrix is a stencil: consecutive rows of a block have the SAME slots shifted by a constant (92 %
+// of the nlpkkt-like matrix's entries, 97 % of the FEM-shaped one's, lie in such rows).  A pattern plan stores a row's
+// slots only where they are not the previous row's plus a constant (the block's pattern table, ptab), and per row where
+// its pattern starts in that table and its shift: 4 bytes per row instead of 2 per entry.  Every lane group fetches its
+// row's pattern (16-byte groups of 8 slots; neighbouring rows share them: cache hits) and writes the row's slots --
+// pattern + shift -- into an LDS array, from which the products read their slot pairs instead of from memory: the same
+// slots, the same products, the same bits.
+struct pat_ctx {
+    unsigned short *slots;          // LDS [CAP + 8]: the block's slots, entry order, from `base` on
+    const uint4 *ptab8;             // the block's pattern table in memory, groups of 8 slots (a row's pattern starts at a group)
+    const unsigned *rinfo;          // per row: first group of its pattern in the block's table | shift << 16
+    const int *row_ptr;
+    int r0, nrows, base, first, end, lanes, seg_lo, seg_hi;
+    unsigned ri;                    // rinfo of this lane group's first row
+};
+
+// slots[at .. at + 8) (those below len) = the pattern group + shift
+__device__ __forceinline__ void pat_write_group(unsigned short *slots, int at, int j0, int len, const uint4 p, int shift) {
+    const unsigned w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (j0 + q < len) slots[at + q] = (unsigned short)(((w[q >> 1] >> (16 * (q & 1))) & 0xffffu) + (unsigned)shift);
+}
+
+// the rows of the block's FIRST pass of lane groups: up to two pattern groups per lane are loaded here (the caller lets
+// them queue behind the value stream) ...
+__device__ __forceinline__ void pat_load_first(const pat_ctx c, uint4 (&p)[2]) {
+    const int my_lane = threadIdx.x % c.lanes, len = c.seg_hi - c.seg_lo, off8 = (int)(c.ri & 0xffffu);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int g = my_lane + k * c.lanes;
+        p[k] = c.ptab8[off8 + (g * 8 < len ? g : 0)];
+    }
+}
+// ... and written here, with whatever is left: longer rows, further passes of rows (blocks of very short rows), and zeros
+// for the halves of the lanes' pairs that lie outside the block (in front of its first entry, behind its last)
+template <int BLOCK, int CAP>
+__device__ __forceinline__ void pat_expand_slots(const pat_ctx c, const uint4 (&p)[2]) {
+    const int t = threadIdx.x;
+    const int my_row = t / c.lanes, my_lane = t % c.lanes, rows_per_pass = BLOCK / c.lanes;
+    int lo = c.seg_lo, hi = c.seg_hi;
+    unsigned ri = c.ri;
+    for (int first = 0; first < c.nrows; first += rows_per_pass) {  // all lanes stay in the loop
+        const int row = first + my_row;
+        if (first > 0) {
+            lo = hi = 0;
+            if (row < c.nrows) {
+                lo = c.row_ptr[c.r0 + row];
+                hi = c.row_ptr[c.r0 + row + 1];
+                ri = c.rinfo[c.r0 + row];
+            }
+        }
+        const int off8 = (int)(ri & 0xffffu), shift = (int)(short)(ri >> 16), len = hi - lo;
+        int g = my_lane;
+        if (first == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k, g += c.lanes)
+                if (g * 8 < len) pat_write_group(c.slots, lo - c.base + g * 8, g * 8, len, p[k], shift);
+        }
+        for (; g * 8 < len; g += c.lanes) pat_write_group(c.slots, lo - c.base + g * 8, g * 8, len, c.ptab8[off8 + g], shift);
+    }
+    constexpr int kUnit = 2 * BLOCK;
+#pragma unroll
+    for (int u = 0; u < CAP / kUnit; ++u) {
+        const int e = c.base + u * kUnit + 2 * t;
+        if (e < c.first || e >= c.end) c.slots[e - c.base] = 0;
+        if (e + 1 < c.first || e + 1 >= c.end) c.slots[e + 1 - c.base] = 0;
+    }
+}
+
+template <typename T, bool NT, int CAP, int ROUNDS>
+__device__ __forceinline__ void local_stage_full_pat(T *stage, const int *__restrict__ my_lines, int last_line,
+                                                     const T *__restrict__ val, const T *__restrict__ x, int e_first,
+                                                     const pat_ctx pc) {
+    using V2 = typename vec2<T>::type;
+    constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
+    const int t = threadIdx.x;
+    int line[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int at = k * kLocalLineQuantum + (t >> 3);
+        line[k] = stream_load<NT>(my_lines + (k == ROUNDS - 1 ? min(at, last_line) : at));
+    }
+    V2 v[kUnits];
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) v[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+    __builtin_amdgcn_sched_barrier(0);
+    // behind the stream: the rows' pattern groups (their addresses came with the row extents, ahead of the stream),
+    // then the x lines
+    uint4 pg[2];
+    pat_load_first(pc, pg);
+    uint4 xl[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const unsigned off = (unsigned)line[k] * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+        xl[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pat_expand_slots<kBlock, CAP>(pc, pg);
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k)
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) = xl[k];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        const unsigned c = *reinterpret_cast<const unsigned *>(pc.slots + u * kUnit + 2 * t);
+        v[u].x *= stage[c & 0xffffu];
+        v[u].y *= stage[c >> 16];
+    }
+    __syncthreads();  // the products take the place of the staged lines
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = v[u];
+}
+
 // STAMP (measurement only, spmv_hip_csr_stamp_blocks): every workgroup leaves {start, end} of the constant 100 MHz
 // clock and the XCD it ran on in stamps[3 * block ..]; the product instantiation (STAMP = false) has no trace of it.
-template <typename T, bool NT, int CAP, bool STAMP = false>
+// PAT: a pattern plan (above) -- lcol is not read; pdesc[b] = {first element of block b's pattern table in ptab (a
+// multiple of 8), elements in it}, rinfo per row, stage_bytes = where the LDS array of the slots begins.
+template <typename T, bool NT, int CAP, bool STAMP = false, bool PAT = false>
 __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int xcd_chunk,
                                                            const int *__restrict__ ids,
                                                            const int4 *__restrict__ desc,
@@ -466,8 +586,12 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
                                                            const unsigned short *__restrict__ lcol,
                                                            const T *__restrict__ val,
                                                            const T *__restrict__ x, T *__restrict__ y,
-                                                           unsigned long long *__restrict__ stamps = nullptr) {
+                                                           unsigned long long *__restrict__ stamps = nullptr, int probe = 0,
+                                                           const int2 *__restrict__ pdesc = nullptr,
+                                                           const unsigned *__restrict__ rinfo = nullptr,
+                                                           const unsigned short *__restrict__ ptab = nullptr, int stage_bytes = 0) {
         using V2 = typename vec2<T>::type;
+    const bool no_slots = STAMP && (probe & 1);  // (measurement only; constant false in the product instantiation)
     unsigned long long t_start = 0;
     if constexpr (STAMP) t_start = __builtin_amdgcn_s_memrealtime();
     constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
@@ -499,16 +623,70 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
     const int units = (d.w - base + kUnit - 1) / kUnit;                       // wave-uniform
     const int rounds = (ld.y + kLocalLineQuantum - 1) / kLocalLineQuantum;    // wave-uniform, 1..8
     const int *my_lines = lines + ld.x;
-    if (units == kUnits) {
+    if constexpr (PAT) {
+        const int2 pd = pdesc[b];
+        pat_ctx pc;
+        pc.slots = reinterpret_cast<unsigned short *>(local_smem + stage_bytes);
+        pc.ptab8 = reinterpret_cast<const uint4 *>(ptab + pd.x);
+        pc.rinfo = rinfo;
+        pc.row_ptr = row_ptr;
+        pc.r0 = r0;
+        pc.nrows = nrows;
+        pc.base = base;
+        pc.first = d.y;
+        pc.end = d.w;
+        pc.lanes = lanes;
+        pc.seg_lo = seg_lo;
+        pc.seg_hi = seg_hi;
+        pc.ri = t / lanes < nrows ? rinfo[r0 + t / lanes] : 0u;
+        if (units == kUnits) {
+            switch (rounds) {
+                case 1: local_stage_full_pat<T, NT, CAP, 1>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+                case 2: local_stage_full_pat<T, NT, CAP, 2>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+                case 3: local_stage_full_pat<T, NT, CAP, 3>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+                case 4: local_stage_full_pat<T, NT, CAP, 4>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+                case 5: local_stage_full_pat<T, NT, CAP, 5>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+                case 6: local_stage_full_pat<T, NT, CAP, 6>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+                case 7: local_stage_full_pat<T, NT, CAP, 7>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+                default: local_stage_full_pat<T, NT, CAP, 8>(stage, my_lines, ld.y - 1, val, x, e_first, pc); break;
+            }
+        } else {
+            // a block cut short: plain loops
+            for (int k = 0; k < rounds; ++k) {
+                const int line = my_lines[min(k * kLocalLineQuantum + (t >> 3), ld.y - 1)];
+                const unsigned off = (unsigned)line * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) =
+                    *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+            }
+            uint4 pg[2];
+            pat_load_first(pc, pg);
+            pat_expand_slots<kBlock, CAP>(pc, pg);
+            __syncthreads();
+            V2 p[kUnits];
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u) {
+                if (u < units) {
+                    const unsigned c = *reinterpret_cast<const unsigned *>(pc.slots + u * kUnit + 2 * t);
+                    p[u] = stream_load<NT>(reinterpret_cast<const V2 *>(val + e_first + u * kUnit));
+                    p[u].x *= stage[c & 0xffffu];
+                    p[u].y *= stage[c >> 16];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u)
+                if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = p[u];
+        }
+    } else if (units == kUnits) {
         switch (rounds) {
-            case 1: local_stage_full<T, NT, CAP, 1>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
-            case 2: local_stage_full<T, NT, CAP, 2>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
-            case 3: local_stage_full<T, NT, CAP, 3>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
-            case 4: local_stage_full<T, NT, CAP, 4>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
-            case 5: local_stage_full<T, NT, CAP, 5>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
-            case 6: local_stage_full<T, NT, CAP, 6>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
-            case 7: local_stage_full<T, NT, CAP, 7>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
-            default: local_stage_full<T, NT, CAP, 8>(stage, my_lines, ld.y - 1, lcol, val, x, e_first); break;
+            case 1: local_stage_full<T, NT, CAP, 1>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
+            case 2: local_stage_full<T, NT, CAP, 2>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
+            case 3: local_stage_full<T, NT, CAP, 3>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
+            case 4: local_stage_full<T, NT, CAP, 4>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
+            case 5: local_stage_full<T, NT, CAP, 5>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
+            case 6: local_stage_full<T, NT, CAP, 6>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
+            case 7: local_stage_full<T, NT, CAP, 7>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
+            default: local_stage_full<T, NT, CAP, 8>(stage, my_lines, ld.y - 1, lcol, val, x, e_first, no_slots); break;
         }
     } else {
         // a block cut short (row cap, line cap, end of the matrix): plain loops

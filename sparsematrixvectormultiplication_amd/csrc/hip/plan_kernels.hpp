@@ -121,4 +121,77 @@ __global__ __launch_bounds__(kBlock) void plan_fill(int segments, const long lon
     }
 }
 
+// ---- the pattern plan of an x-window plan (csr_stream_local<.., PAT>): one workgroup per block.
+// pat_mark: rowflag[r] = 0x10000 | (delta & 0xffff) when row r's slots are the previous row's (same block, same length)
+// plus the constant delta, else 0 (its slots go into the block's pattern table); pcount[b] = slots in that table (even).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void pat_mark(int blocks, const int4 *__restrict__ desc, const int *__restrict__ row_ptr,
+                                                  const unsigned short *__restrict__ slot, int *__restrict__ rowflag,
+                                                  int *__restrict__ pcount) {
+    __shared__ int cnt;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= blocks) return;
+    const int4 d = desc[b];
+    const int r0 = d.x, nrows = d.z;
+    if (t == 0) cnt = 0;
+    __syncthreads();
+    for (int i = t; i < nrows; i += BLOCK) {
+        const int s = row_ptr[r0 + i], len = row_ptr[r0 + i + 1] - s;
+        bool derived = false;
+        int delta = 0;
+        if (i > 0 && len > 0) {
+            const int ps = row_ptr[r0 + i - 1];
+            if (s - ps == len) {
+                delta = (int)slot[s] - (int)slot[ps];
+                derived = true;
+                for (int j = 1; j < len; ++j)
+                    if ((int)slot[s + j] - (int)slot[ps + j] != delta) {
+                        derived = false;
+                        break;
+                    }
+            }
+        }
+        rowflag[r0 + i] = derived ? (0x10000 | (delta & 0xffff)) : 0;
+        if (!derived && len > 0) atomicAdd(&cnt, (len + 7) & ~7);  // a row's pattern: whole groups of 8 slots
+    }
+    __syncthreads();
+    if (t == 0) pcount[b] = cnt;
+}
+// pat_fill: rinfo[r] = the group of 8 slots at which the row's pattern starts in the block's table | shift << 16 (a row that is its predecessor
+// shifted shares the predecessor's pattern, its shift the sum of the deltas since); the table itself; pdesc[b] = {first
+// element in ptab, elements}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void pat_fill(int blocks, const int4 *__restrict__ desc, const int *__restrict__ row_ptr,
+                                                  const unsigned short *__restrict__ slot, const int *__restrict__ rowflag,
+                                                  const long long *__restrict__ pbase, unsigned *__restrict__ rinfo,
+                                                  unsigned short *__restrict__ ptab, int2 *__restrict__ pdesc) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= blocks) return;
+    const int4 d = desc[b];
+    const int r0 = d.x, nrows = d.z;
+    const long long pb = pbase[b];
+    if (t == 0) {
+        int filled = 0, cur = 0, shift = 0;
+        for (int i = 0; i < nrows; ++i) {
+            const int f = rowflag[r0 + i];
+            if (f & 0x10000) {
+                shift += (int)(short)(f & 0xffff);
+            } else {
+                cur = filled;  // (in groups of 8 slots)
+                shift = 0;
+                filled += (row_ptr[r0 + i + 1] - row_ptr[r0 + i] + 7) >> 3;
+            }
+            rinfo[r0 + i] = (unsigned)cur | ((unsigned)(shift & 0xffff) << 16);
+        }
+        pdesc[b] = make_int2((int)pb, filled * 8);
+    }
+    __syncthreads();
+    for (int i = t; i < nrows; i += BLOCK) {
+        if (rowflag[r0 + i] & 0x10000) continue;
+        const int s = row_ptr[r0 + i], len = row_ptr[r0 + i + 1] - s;
+        const long long o = pb + 8 * (long long)(rinfo[r0 + i] & 0xffffu);
+        for (int j = 0; j < len; ++j) ptab[o + j] = slot[s + j];
+    }
+}
+
 }  // namespace spmv

@@ -792,6 +792,90 @@ int csr_tune_placement(spmv_csr_dev *m) {
     return rc;
 }
 
+// The pattern plan of a handle's x-window plan (csr_kernels.hpp, PAT; plan_kernels.hpp): built on the device from the
+// plan's own arrays, whichever builder made them.  auto: kept when the tables hold at most a quarter of the slots.
+// Where it pays (same handle, same placement, the two instantiations alternately: profiles/r3_ab_patterns.txt): the
+// nlpkkt-like matrix 190 -> 178 us (bench.py over 4 uploads each; 204 -> 185 on a slow placement), a 27-point stencil
+// 197 -> 190; neutral on the FEM-shaped matrix (75 per row: 155 / 157) and on nlpkkt80-size (59 / 60); a loss where the
+// rows are short -- several rows per lane group, their patterns fetched pass after pass: 7-point 271 -> 285, 5-point
+// 186 -> 210 --, in fp32 (124 -> 133: the same LDS work for half the bytes) and for matrices that live in the Infinity
+// Cache (cant-size 10.8 -> 12.4).  What it costs is mostly LDS: 4 KB more per workgroup is one workgroup less per CU.
+// Hence auto: fp64, streamed matrices (the `nt` threshold), 16 to 64 entries per row on average, tables of at most a
+// quarter of the slots.
+int csr_build_patterns(spmv_csr_dev *m) {
+    if (g_local_patterns == 0 || m->local_blocks <= 0 || !m->lcol || !m->ldesc4 || !m->row_ptr || m->M_local <= 0) return 0;
+    if (g_local_patterns < 0 && (m->value_bytes != 8 || m->nz * 10LL <= (128LL << 20) || m->nz < 16LL * m->M_local ||
+                                 m->nz > 64LL * m->M_local))
+        return 0;
+    UploadTrace trace("csr_build_patterns");
+    const int B = m->local_blocks;
+    int *rowflag = nullptr, *pcount = nullptr;
+    long long *pbase = nullptr;
+    auto drop_tmp = [&] {
+        (void)hipFree(rowflag);
+        (void)hipFree(pcount);
+        (void)hipFree(pbase);
+    };
+    hipError_t e = hipMalloc((void **)&rowflag, (size_t)m->M_local * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&pcount, (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&pbase, (size_t)B * sizeof(long long));
+    if (e == hipSuccess) e = hipMemsetAsync(rowflag, 0, (size_t)m->M_local * sizeof(int), g_stream);
+    if (e != hipSuccess) {
+        drop_tmp();
+        return fail("pattern plan: allocation failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((pat_mark<256>), dim3(B), dim3(256), 0, g_stream, B, m->ldesc4, m->row_ptr, m->lcol, rowflag, pcount);
+    std::vector<int> h_count((size_t)B);
+    e = hipMemcpyAsync(h_count.data(), pcount, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) {
+        drop_tmp();
+        return fail("pattern plan: marking the rows failed: %s", hipGetErrorString(e));
+    }
+    std::vector<long long> h_base((size_t)B);
+    long long total = 0;
+    int widest = 0;
+    for (int b = 0; b < B; ++b) {
+        h_base[(size_t)b] = total;
+        total += h_count[(size_t)b];
+        widest = std::max(widest, h_count[(size_t)b]);
+    }
+    trace.mark("rows marked");
+    // (auto) a plan whose tables hold more than a quarter of the slots keeps reading the slot stream
+    if ((g_local_patterns < 0 && total * 4 > m->nz) || total > 0x7ffffff0LL) {
+        drop_tmp();
+        return 0;
+    }
+    e = hipMalloc((void **)&m->ptab, ((size_t)total + 1024) * sizeof(unsigned short));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->rinfo, (size_t)m->M_local * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->pdesc, (size_t)B * sizeof(int2));
+    if (e == hipSuccess) e = hipMemsetAsync(m->ptab, 0, ((size_t)total + 1024) * sizeof(unsigned short), g_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->rinfo, 0, (size_t)m->M_local * sizeof(unsigned), g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pbase, h_base.data(), (size_t)B * sizeof(long long), hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((pat_fill<256>), dim3(B), dim3(256), 0, g_stream, B, m->ldesc4, m->row_ptr, m->lcol, rowflag, pbase, m->rinfo,
+                           m->ptab, m->pdesc);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    drop_tmp();
+    if (e != hipSuccess) {
+        (void)hipFree(m->ptab);
+        (void)hipFree(m->rinfo);
+        (void)hipFree(m->pdesc);
+        m->ptab = nullptr;
+        m->rinfo = nullptr;
+        m->pdesc = nullptr;
+        return fail("pattern plan: building the tables failed: %s", hipGetErrorString(e));
+    }
+    m->pat_slots = total;
+    m->pat_max = widest;
+    m->device_bytes += ((size_t)total + 1024) * 2 + (size_t)m->M_local * 4 + (size_t)B * 8;
+    trace.mark("tables");
+    return 0;
+}
+
 template <typename T>
 int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const T *values, int row0,
                     int row1, spmv_csr_dev **out, int *adopt_col = nullptr, T *adopt_val = nullptr) {
@@ -1003,6 +1087,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
             m->local_lines = (long long)local.lines.size() - kLocalLinesMax;
         }
     }
+    if (!rc && m->local_blocks > 0) rc |= csr_build_patterns(m);
     if (!rc && !m->col) rc |= upload_array(&m->col, col_idx ? col_idx + e0 : nullptr, (size_t)nz, kPad);
     if (!rc && !m->val) rc |= upload_array((T **)&m->val, values ? values + e0 : nullptr, (size_t)nz, kPad);
     if (!rc) rc |= upload_array(&m->desc, desc.data(), desc.size(), 1);
@@ -1489,6 +1574,9 @@ extern "C" void spmv_hip_csr_free(spmv_csr_dev *m) {
     (void)hipFree(m->ldesc);
     (void)hipFree(m->lines);
     (void)hipFree(m->lcol);
+    (void)hipFree(m->ptab);
+    (void)hipFree(m->rinfo);
+    (void)hipFree(m->pdesc);
     for (spmv_csr_dev::long_tiles *tier : {&m->mt}) {
         (void)hipFree(tier->block_row);
         (void)hipFree(tier->block_pass);
@@ -1633,6 +1721,10 @@ extern "C" int spmv_hip_csr_stamp_blocks(spmv_csr_dev *m, int warm, unsigned lon
     const size_t bytes = (size_t)m->local_blocks * 3 * sizeof(unsigned long long);
     HIP_TRY(hipMalloc((void **)&d, bytes));
     int rc = 0;
+    // (warm >= 1000, measurement only: the stamped launch does not read the slot stream -- the time the kernel would take
+    // if the slots came from a per-block pattern; y is then wrong)
+    const int probe = warm >= 1000 ? 1 : 0;
+    warm %= 1000;
     for (int i = 0; i < warm && !rc; ++i) rc = csr_launch_any(m, SPMV_CSR_STREAM, m->x, m->y, g_stream);
     if (!rc) {
         const int lcount = m->local_blocks;
@@ -1644,11 +1736,11 @@ extern "C" int spmv_hip_csr_stamp_blocks(spmv_csr_dev *m, int warm, unsigned lon
         if (lnt)
             hipLaunchKernelGGL((csr_stream_local<double, true, 2048, true>), dim3(lgrid), dim3(kBlock), lds, g_stream, lcount, lchunk,
                                (const int *)nullptr, m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const double *)m->val,
-                               (const double *)m->x, y, d);
+                               (const double *)m->x, y, d, probe);
         else
             hipLaunchKernelGGL((csr_stream_local<double, false, 2048, true>), dim3(lgrid), dim3(kBlock), lds, g_stream, lcount, lchunk,
                                (const int *)nullptr, m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const double *)m->val,
-                               (const double *)m->x, y, d);
+                               (const double *)m->x, y, d, probe);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
         if (e == hipSuccess) e = hipMemcpy(stamps_host, d, bytes, hipMemcpyDeviceToHost);
@@ -1758,12 +1850,13 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->place_best_us = m->place_best_us;
     out->val_address = (unsigned long long)(uintptr_t)m->val;
     out->tile_expanded_entries = m->xe && m->expansion ? (long long)m->expansion->entries : 0;
+    out->pattern_slots = m->ptab ? m->pat_slots : 0;
     out->stream_kernel = m->local_blocks > 0 ? 1 : m->tile_blocks > 0 ? 3
                          : ((m->stream_cap == 4096 || m->stream_cap == 2048) && m->M_local > 0 &&
                             m->nz < (long long)m->M_local * (m->stream_cap / kBlock)) ? 2 : 0;
-    if (m->local_blocks > 0)
-        out->stream_bytes = m->nz * (vb + 2) + 4 * m->local_lines + 24LL * m->local_blocks +
-                            4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
+    if (m->local_blocks > 0)  // (a pattern plan: the tables and 4 bytes per row instead of 2 bytes per entry)
+        out->stream_bytes = m->nz * vb + (m->ptab ? 2 * m->pat_slots + 4LL * m->M_local + 8LL * m->local_blocks : 2 * m->nz) +
+                            4 * m->local_lines + 24LL * m->local_blocks + 4LL * (m->M_local + 1) + vb * m->M_local + vb * m->N;
     else if (m->tile_blocks > 0) {  // tiles: 4-byte column + 2-byte key + value per (padded) entry; rows beyond the limit as CSR
         out->stream_bytes = m->tile_padded * (vb + 6) - (m->tile_packed ? 2 : 0) * m->tile_staged + 16LL * m->tile_passes +
                             4LL * m->tile_blocks +
@@ -1957,9 +2050,20 @@ int csr_launch(const spmv_csr_dev *m, int variant, const T *x, T *y_full, hipStr
                     const int lgrid = lchunk > 0 ? (lcount + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk) : lcount;
                     if (lcount > 0) {
                     const size_t lds = std::max((size_t)m->local_cap * sizeof(T), (size_t)m->local_stage_lines * kLineBytes);
+                    // a pattern plan: the slots are rebuilt in LDS (behind the stage) from the block's pattern table, not read
+                    // entry by entry
+                    const bool patterns = m->ptab && m->rinfo && m->pdesc && g_local_patterns != 0;
+                    const size_t pat_lds = lds + ((size_t)m->local_cap + 8) * sizeof(unsigned short);
 #define SPMV_LOCAL(NT, CAP)                                                                                   \
-    hipLaunchKernelGGL((csr_stream_local<T, NT, CAP>), dim3(lgrid), dim3(kBlock), lds, s, lcount, lchunk, lids,   \
-                       m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const T *)m->val, x, y)
+    do {                                                                                                      \
+        if (patterns)                                                                                         \
+            hipLaunchKernelGGL((csr_stream_local<T, NT, CAP, false, true>), dim3(lgrid), dim3(kBlock), pat_lds, s, lcount, lchunk, \
+                               lids, m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const T *)m->val, x, y, \
+                               (unsigned long long *)nullptr, 0, m->pdesc, m->rinfo, m->ptab, (int)lds);       \
+        else                                                                                                  \
+            hipLaunchKernelGGL((csr_stream_local<T, NT, CAP>), dim3(lgrid), dim3(kBlock), lds, s, lcount, lchunk, lids, \
+                               m->ldesc4, m->ldesc, m->lines, m->row_ptr, m->lcol, (const T *)m->val, x, y);   \
+    } while (0)
                     // streamed-once hint only when the matrix cannot live in the 256 MiB Infinity Cache anyway
                     // (cant-like, 53 MB: 10.9 us without it, 11.7 us with; fem-large: 160 vs 151 us)
                     const bool lnt = g_local_nt < 0 ? m->nz * (long long)(sizeof(T) + 2) > (128LL << 20) : g_local_nt != 0;

@@ -104,6 +104,7 @@ int g_tile_fit = 1;
 int g_tile_streams = 1;
 int g_tile_places = 0;
 int g_tile_min_pass = 256;
+int g_local_patterns = -1;
 int g_tile_mid_items = 0;
 int g_tile_items = 1008;  // two rounds of the 512 places: 1.222 ms on the power-law matrix against 1.248 with 4096, 1.231 with 504
 int g_tile_pack = 1;
@@ -254,6 +255,8 @@ extern "C" int spmv_hip_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "tile_items")) {
         if (value < 8 || value > 65536) return fail("set_tuning: tile_items must be 8..65536");
         g_tile_items = value;
+    } else if (!strcmp(key, "local_patterns")) {
+        g_local_patterns = value < 0 ? -1 : value != 0;  // read at upload (the plan) and at launch (0: the slot stream)
     } else if (!strcmp(key, "tile_mid_items")) {
         if (value < 0 || value > 65536) return fail("set_tuning: tile_mid_items must be 0 (auto: three rounds of the CUs) .. 65536");
         g_tile_mid_items = value;

@@ -66,6 +66,7 @@ extern int g_tile_long;       // 1: the rows beyond the tile limit get a tile pl
 extern int g_tile_pack;       // 1: passes that can be staged store head | row | column offset in one 32-bit word (no key read)
 extern int g_tile_density;    // a pass is staged when it holds at least one entry per this many columns of its window
 extern int g_tile_mid_lo;     // a scattered matrix's rows longer than this (up to tile_lmax) form the middle tier ("tile_mid_lo")
+extern int g_local_patterns;  // x-window plans: -1 auto (a pattern plan where it holds a quarter of the slots at most), 0 never, 1 always ("local_patterns")
 extern int g_tile_expand;     // plans with gather passes: -1 auto, 0 never, 1 always: x expanded into entry order ahead of csr_tile ("tile_expand")
 extern int g_tile_gather_ahead;  // 1: plans with gather passes run the csr_tile instantiation that gathers one pass early
 extern int g_tile_mid;        // 1: scattered plans get that tier (when it holds >= 2^22 entries), 0: never
@@ -193,6 +194,13 @@ struct spmv_csr_dev {
     int2 *ldesc = nullptr;            // [local_blocks] {first line in `lines`, line count}
     int *lines = nullptr;             // x line ids, block after block, ascending inside a block
     unsigned short *lcol = nullptr;   // [nz + pad] slot of each entry in its block's staged lines
+    // the pattern plan (round 3; csr_kernels.hpp, PAT): where most rows of the blocks are their predecessor shifted by a
+    // constant, the kernel rebuilds the slots from a table per block and 4 bytes per row instead of reading lcol
+    unsigned short *ptab = nullptr;   // [pat_slots + pad] the blocks' pattern tables
+    unsigned *rinfo = nullptr;        // [M_local] start of the row's pattern in its block's table | shift << 16
+    int2 *pdesc = nullptr;            // [local_blocks] {first element in ptab (even), elements}
+    long long pat_slots = 0;          // elements of all tables
+    int pat_max = 0;                  // the largest table (elements): LDS for it
     int local_blocks = 0;             // 0: no plan (not profitable / not possible)
     int local_stage_lines = 0;        // LDS stage: most lines any block lists, in steps of 32
     int local_cap = 2048;

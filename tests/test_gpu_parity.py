@@ -1236,6 +1236,64 @@ def test_column_split_emulated_ranks(gpu, oracle):
         assert whole.get_y().tobytes() == y_ref.tobytes()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pattern_plan_rebuilds_the_slots_bit_for_bit(gpu, oracle, dtype):
+    """Round 3: where most rows of an x-window block are their predecessor shifted by a constant (stencils), the kernel
+    does not read the 16-bit slot of every entry: upload keeps one pattern table per block and 4 bytes per row, the
+    kernel rebuilds the block's slots from them in LDS.  The same slots, hence the same products in the same order: the
+    bits of the kernel that reads the slot stream ("local_patterns" 0 at launch: the same handle).  Cases: the KKT-shaped
+    stencil (auto: plan kept), a band with random columns (auto: not kept; forced: every row its own pattern), blocks of
+    very short rows (several row passes per block), empty rows, a row block of a bigger matrix."""
+    from sparsematrixvectormultiplication_amd import synth
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    from _util import banded_csr
+    rng = np.random.default_rng(91)
+
+    def run(M, N, rp, col, val, forced, expect_plan, row0=0, row1=None):
+        x = rng.uniform(-1, 1, N).astype(dtype)
+        ref = (oracle.csr_serial if dtype == np.float64 else oracle.csr_f32_accum64)(rp, col, val, x)
+        set_tuning("local_patterns", 1 if forced else -1)
+        try:
+            with sp.CsrDevice(M, N, rp, col, val, row0=row0, row1=M if row1 is None else row1) as dev:
+                info = dev.info()
+                assert info["local_blocks"] > 0
+                assert (info["pattern_slots"] > 0) == expect_plan, info["pattern_slots"]
+                lo, hi = row0, M if row1 is None else row1
+                sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * x.itemsize)
+                y = dev.spmv(x, sp.CSR_STREAM)[lo:hi].copy()
+                tol = 1e-10 if dtype == np.float64 else 1e-5
+                assert np.max(np.abs(y.astype(np.float64) - ref[lo:hi])) <= tol * max(np.max(np.abs(ref)), 1e-300)
+                set_tuning("local_patterns", 0)                   # the same handle through the slot stream
+                y0 = dev.spmv(x, sp.CSR_STREAM)[lo:hi].copy()
+                assert y.tobytes() == y0.tobytes()
+                return info
+        finally:
+            set_tuning("local_patterns", -1)
+
+    M, rp, col, val = synth.kkt_like((24, 24, 25), 5)
+    val = val.astype(dtype)
+    info = run(M, M, rp, col, val, True, True)
+    assert info["pattern_slots"] * 4 <= rp[-1]                    # a stencil: the tables hold a fraction of the slots
+    run(M, M, rp, col, val, True, True, row0=M // 3, row1=2 * M // 3)
+    run(M, M, rp, col, val, False, False)                         # auto: a matrix of this size lives in the cache
+    if dtype == np.float64:                                       # auto keeps it: fp64, streamed, 28 per row
+        Mb, rpb, colb, valb = synth.kkt_like((64, 64, 66), 5)
+        assert rpb[-1] * 10 > (128 << 20)
+        run(Mb, Mb, rpb, colb, valb, False, True)
+    rp2, col2, val2 = banded_csr(rng, 20000, 20000, 22, 150)       # random columns inside a band: no two rows alike
+    run(20000, 20000, rp2, col2, val2.astype(dtype), False, False)
+    run(20000, 20000, rp2, col2, val2.astype(dtype), True, True)
+    # very short rows (hundreds of rows per block: several row passes), every 7th row empty, a diagonal band
+    n = 60000
+    lens = np.where(np.arange(n) % 7 == 3, 0, 3)
+    rp3 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(n), lens)
+    col3 = np.clip(rows + np.tile([-1, 0, 1], n)[:rp3[-1]], 0, n - 1).astype(np.int32)
+    order = np.lexsort((col3, rows))
+    val3 = rng.uniform(-1, 1, rp3[-1]).astype(dtype)
+    run(n, n, rp3, col3[order], val3, True, True)
+
+
 def test_power_iteration_halo_single_rank_communicator(gpu):
     """The RCCL side at world size 1: setup (all-gather of the needs record), an exchange with no peers, the
     all-reduce of the norm; the halo loop then gives the plain loop's result bit for bit."""
