@@ -121,7 +121,9 @@ __global__ __launch_bounds__(kCutBlock) void tile_cut_passes(int B, const int *_
                                                              int *__restrict__ ent_len, const int *__restrict__ pass_off,
                                                              const int *__restrict__ rem_off, const int *__restrict__ ent_off,
                                                              int4 *__restrict__ pass_desc, int2 *__restrict__ pass_src,
-                                                             unsigned long long *__restrict__ rem_keys, int *__restrict__ failed) {
+                                                             unsigned long long *__restrict__ rem_keys, int *__restrict__ failed,
+                                                             int4 *__restrict__ rec = nullptr, const int *__restrict__ rec_off = nullptr,
+                                                             int *__restrict__ n_rec = nullptr) {
     __shared__ int red[4];
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -129,6 +131,18 @@ __global__ __launch_bounds__(kCutBlock) void tile_cut_passes(int B, const int *_
     const int key0 = kb[b], n = kb[b + 1] - key0;
     const unsigned long long *K = keys + key0;
     int passes = 0, rems = 0, ent = 0;  // the same in every thread
+    // COUNT with rec: every step of the walk is written down -- a pass {i, j, entries before it, its ordinal}, a window
+    // that goes to the remainder {i, w, remainder entries before it, -1} -- so that the descriptors can be filled in
+    // without walking the block a second time (tile_fill_from_records); a block with more steps than its share of rec
+    // holds reports that (n_rec[b] = -1) and the caller walks again
+    int steps = 0;
+    const int rec_base = (!FILL && rec) ? rec_off[b] : 0, rec_cap = (!FILL && rec) ? rec_off[b + 1] - rec_off[b] : 0;
+    auto record = [&](int i, int j, int before, int ordinal) {
+        if (!FILL && rec) {
+            if (steps < rec_cap && t == 0) rec[rec_base + steps] = int4{i, j, before, ordinal};
+            ++steps;
+        }
+    };
     const int pbase = FILL ? pass_off[b] : 0, rbase = FILL ? rem_off[b] : 0, ebase = FILL ? ent_off[b] : 0;
     auto col_of = [&](int idx) { return (int)(K[idx] >> 32); };
     auto emit = [&](int i, int j) {
@@ -143,6 +157,7 @@ __global__ __launch_bounds__(kCutBlock) void tile_cut_passes(int B, const int *_
             pass_desc[pbase + passes] = int4{ebase + ent, count, wbase, staged ? (wlen | (P.pack ? kTilePassPacked : 0)) : 0};
             pass_src[pbase + passes] = int2{key0 + i, b};
         }
+        record(i, j, ent, passes);
         ++passes;
         ent += (count + 3) & ~3;
     };
@@ -158,6 +173,9 @@ __global__ __launch_bounds__(kCutBlock) void tile_cut_passes(int B, const int *_
                 const int cap = min(n, i + P.chunk);
                 const long long limit = base + P.win_cols;
                 // sorted ascending: the entries below the window's end are a prefix of [i, cap)
+                // (the candidate range's columns copied to LDS first -- one trip to memory per step instead of three
+                // dependent ones -- was measured and is no faster: 54.7 against 49.9 ms for config 5's long rows; a step
+                // costs its barriers, not its loads)
                 int c = 0;
                 for (int idx = i + t; idx < i + P.chunk; idx += kCutBlock) {  // (the same trip count for all lanes)
                     const bool in = idx < cap && (long long)col_of(min(idx, cap - 1)) < limit;
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(kCutBlock) void tile_cut_passes(int B, const int *_
                             rem_keys[(size_t)rbase + rems + (idx - i)] = (lrow << (32 + P.pos_bits)) | ((k >> 32) << P.pos_bits) | pos;
                         }
                     }
+                    record(i, w, rems, -1);
                     rems += c;
                     i = w;
                     continue;
@@ -197,6 +216,54 @@ __global__ __launch_bounds__(kCutBlock) void tile_cut_passes(int B, const int *_
         n_pass[b] = passes;
         n_rem[b] = rems;
         ent_len[b] = ent;
+        if (rec) n_rec[b] = steps <= rec_cap ? steps : -1;
+    }
+}
+
+// What tile_cut_passes<true> writes, from the steps tile_cut_passes<false> wrote down: one workgroup per block, a
+// thread per pass record; the remainder windows' keys copied by all threads, window after window.
+__global__ __launch_bounds__(kCutBlock) void tile_fill_from_records(int B, const int *__restrict__ kb,
+                                                                    const unsigned long long *__restrict__ keys, CutParams P,
+                                                                    const int4 *__restrict__ rec, const int *__restrict__ rec_off,
+                                                                    const int *__restrict__ n_rec, const int *__restrict__ pass_off,
+                                                                    const int *__restrict__ rem_off, const int *__restrict__ ent_off,
+                                                                    int4 *__restrict__ pass_desc, int2 *__restrict__ pass_src,
+                                                                    unsigned long long *__restrict__ rem_keys) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int t = threadIdx.x;
+    const int key0 = kb[b];
+    const unsigned long long *K = keys + key0;
+    const int pbase = pass_off[b], rbase = rem_off[b], ebase = ent_off[b];
+    const int4 *R = rec + rec_off[b];
+    const int steps = n_rec[b];
+    bool any_pass = false;
+    for (int r = t; r < steps; r += kCutBlock) {
+        const int4 d = R[r];
+        if (d.w < 0) continue;
+        const int i = d.x, j = d.y, count = j - i, cmin = (int)(K[i] >> 32), cmax = (int)(K[j - 1] >> 32);
+        const int wbase = cmin & ~3;
+        int wlen = ((cmax - wbase + 1) + 3) & ~3;
+        wlen = min(wlen, (P.col_top - wbase + P.kper - 1) / P.kper * P.kper);
+        const bool staged = wlen <= P.win_cols && wlen <= (int)kTilePackColMask + 1 && (P.pack || (long long)count * P.density >= wlen);
+        pass_desc[pbase + d.w] = int4{ebase + d.z, count, wbase, staged ? (wlen | (P.pack ? kTilePassPacked : 0)) : 0};
+        pass_src[pbase + d.w] = int2{key0 + i, b};
+        any_pass = true;
+    }
+    const unsigned long long pos_mask = (1ull << P.pos_bits) - 1;
+    for (int r = 0; r < steps; ++r) {  // (the same records for every thread)
+        const int4 d = R[r];
+        if (d.w >= 0) continue;
+        for (int idx = d.x + t; idx < d.y; idx += kCutBlock) {
+            const unsigned long long k = K[idx];
+            const unsigned long long lrow = (k & 0xffffffffull) >> P.pos_bits, pos = k & pos_mask;
+            rem_keys[(size_t)rbase + d.z + (idx - d.x)] = (lrow << (32 + P.pos_bits)) | ((k >> 32) << P.pos_bits) | pos;
+        }
+    }
+    // a block without entries in passes: one pass of none (ent_off[b + 1] - ent_off[b] = 0 then)
+    if (__syncthreads_or(any_pass) == 0 && t == 0) {
+        pass_desc[pbase] = int4{ebase, 0, 0, P.pack ? (P.kper | kTilePassPacked) : 0};
+        pass_src[pbase] = int2{key0, b};
     }
 }
 
@@ -413,12 +480,24 @@ int tile_build_device(int M, int N, const TileDevInput<T> &in, const int *h_row_
     trace.mark("segmented sort");
     // 3. cuts: count, prefix sums on the host (three ints per block), fill
     CutParams P{chunk, win_cols, density, pack ? min_pass : 0, pos_bits, std::max(N, 1), 16 / (int)sizeof(T), pack ? 1 : 0};
+    // (the walk writes its steps down -- room for one step per 32 keys of a block and 64 more -- so that filling in the
+    // descriptors needs no second walk: config 5's long rows 2 x 50 ms -> 50 ms)
+    std::vector<int> rec_off((size_t)B + 1, 0);
+    for (int b = 0; b < B; ++b) rec_off[(size_t)b + 1] = rec_off[(size_t)b] + (kb[(size_t)b + 1] - kb[(size_t)b]) / 32 + 64;
+    int4 *d_rec = nullptr;
+    int *d_rec_off = nullptr, *d_n_rec = nullptr;
+    e = tmp.alloc(&d_rec, (size_t)rec_off[(size_t)B]);
+    if (e == hipSuccess) e = tmp.alloc(&d_rec_off, (size_t)B + 1);
+    if (e == hipSuccess) e = tmp.alloc(&d_n_rec, (size_t)B);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rec_off, rec_off.data(), rec_off.size() * sizeof(int), hipMemcpyHostToDevice, s);
+    if (bad(e, "allocation")) return -1;
     hipLaunchKernelGGL((tile_cut_passes<false>), dim3(B), dim3(kCutBlock), 0, s, B, d_kb, sorted, P, d_counts, d_counts + B,
                        d_counts + 2 * (size_t)B, (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, (int4 *)nullptr,
-                       (int2 *)nullptr, (unsigned long long *)nullptr, d_failed);
-    std::vector<int> counts(3 * (size_t)B);
+                       (int2 *)nullptr, (unsigned long long *)nullptr, d_failed, d_rec, (const int *)d_rec_off, d_n_rec);
+    std::vector<int> counts(3 * (size_t)B), n_rec((size_t)B);
     int failed = 0;
     e = hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(n_rec.data(), d_n_rec, n_rec.size() * sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&failed, d_failed, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (bad(e, "counting the passes")) return -1;
@@ -462,8 +541,14 @@ int tile_build_device(int M, int N, const TileDevInput<T> &in, const int *h_row_
     if (e == hipSuccess) e = hipMemcpyAsync(d_offs, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice, s);
     if (bad(e, "allocating the plan")) return -1;
     const int *d_pass_off = d_offs, *d_rem_off = d_offs + B + 1, *d_ent_off = d_offs + 2 * ((size_t)B + 1);
-    hipLaunchKernelGGL((tile_cut_passes<true>), dim3(B), dim3(kCutBlock), 0, s, B, d_kb, sorted, P, (int *)nullptr, (int *)nullptr,
-                       (int *)nullptr, d_pass_off, d_rem_off, d_ent_off, d_pass_desc, d_pass_src, d_rem_a, d_failed);
+    bool all_recorded = true;
+    for (int b = 0; b < B; ++b) all_recorded = all_recorded && n_rec[(size_t)b] >= 0;
+    if (all_recorded)
+        hipLaunchKernelGGL(tile_fill_from_records, dim3(B), dim3(kCutBlock), 0, s, B, d_kb, sorted, P, (const int4 *)d_rec,
+                           (const int *)d_rec_off, (const int *)d_n_rec, d_pass_off, d_rem_off, d_ent_off, d_pass_desc, d_pass_src, d_rem_a);
+    else  // (a block of passes of a few entries each: the second walk)
+        hipLaunchKernelGGL((tile_cut_passes<true>), dim3(B), dim3(kCutBlock), 0, s, B, d_kb, sorted, P, (int *)nullptr, (int *)nullptr,
+                           (int *)nullptr, d_pass_off, d_rem_off, d_ent_off, d_pass_desc, d_pass_src, d_rem_a, d_failed);
     trace.mark("cuts: fill");
     // 4. the passes' entries
     if (total_pass > 0) {
