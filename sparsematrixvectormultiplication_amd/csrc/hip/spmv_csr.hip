@@ -799,7 +799,7 @@ int csr_tune_placement(spmv_csr_dev *m) {
 // 197 -> 190; neutral on the FEM-shaped matrix (75 per row: 155 / 157) and on nlpkkt80-size (59 / 60); a loss where the
 // rows are short -- several rows per lane group, their patterns fetched pass after pass: 7-point 271 -> 285, 5-point
 // 186 -> 210 --, in fp32 (124 -> 133: the same LDS work for half the bytes) and for matrices that live in the Infinity
-// Cache (cant-size 10.8 -> 12.4).  What it costs is mostly LDS: 4 KB more per workgroup is one workgroup less per CU.
+// Cache (cant-size 10.8 -> 12.4).  The gain goes with the placement of the arrays: 1-2 % on a fast one, 9 % on a slow one.
 // Hence auto: fp64, streamed matrices (the `nt` threshold), 16 to 64 entries per row on average, tables of at most a
 // quarter of the slots.
 int csr_build_patterns(spmv_csr_dev *m) {

@@ -71,6 +71,6 @@ for name, gen, dtype in cases:
                 ys[p] = dev.get_y().copy()
         set_tuning("local_patterns", int(os.environ.get("PATTERNS", "1")))
         same = ys[0].tobytes() == ys[1].tobytes()
-        print(f"{name}: nnz={int(rp[-1])} pattern slots {info.get('pattern_slots', '?')} | slot stream "
+        print(f"{name}: nnz={int(rp[-1])} blocks {info['local_blocks']} stage lines {info['local_stage_lines']} pattern slots {info.get('pattern_slots', '?')} | slot stream "
               f"{' '.join(f'{v:.1f}' for v in rows[0])} (mean {np.mean(rows[0]):.1f}) | pattern plan "
               f"{' '.join(f'{v:.1f}' for v in rows[1])} (mean {np.mean(rows[1]):.1f}) us | same bits: {same}", flush=True)
