@@ -169,8 +169,8 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
  *                     "local_patterns" -1 | 0 | 1 (read at upload and at launch) x-window plans: the kernel rebuilds a block's
- *                         slots from a pattern table instead of reading them -- auto: where the tables hold at most a
- *                         quarter of the slots (stencil-like matrices); 0 never; 1 always
+ *                         slots from a pattern table instead of reading them -- auto: fp64 matrices of more than 512 MB with 16-64
+ *                         entries per row whose tables hold at most a quarter of the slots (large stencils); 0 never; 1 always
  *                     "tile_mid_items" (0 = three rounds of the CUs) work items of the middle tier
  *                     "tile_expand" -1 | 0 | 1 (read at upload and at launch) a tile plan with gather passes runs on an
  *                         expanded x -- auto: from 2^22 entries on when under a tenth of them are staged, fp32 always, fp64

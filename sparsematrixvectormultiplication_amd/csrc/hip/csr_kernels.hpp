@@ -474,12 +474,34 @@ struct pat_ctx {
     unsigned ri;                    // rinfo of this lane group's first row
 };
 
-// slots[at .. at + 8) (those below len) = the pattern group + shift
+// slots[at .. at + 8) (those below len) = the pattern group + shift.  Written as PAIRS wherever a pair lies on a 4-byte
+// boundary of the LDS array (a row starts at an even or an odd entry of its block): four or five LDS writes per group
+// instead of eight -- these writes are most of what a pattern plan costs.
+typedef unsigned short pat_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pat_shifted(unsigned pair, unsigned shift2) {  // both halves + shift (v_pk_add_u16)
+    const pat_u16x2 a = __builtin_bit_cast(pat_u16x2, pair), b = __builtin_bit_cast(pat_u16x2, shift2);
+    return __builtin_bit_cast(unsigned, (pat_u16x2)(a + b));
+}
 __device__ __forceinline__ void pat_write_group(unsigned short *slots, int at, int j0, int len, const uint4 p, int shift) {
-    const unsigned w[4] = {p.x, p.y, p.z, p.w};
+    const unsigned shift2 = ((unsigned)shift & 0xffffu) * 0x10001u;
+    const unsigned w[4] = {pat_shifted(p.x, shift2), pat_shifted(p.y, shift2), pat_shifted(p.z, shift2), pat_shifted(p.w, shift2)};
+    const int left = len - j0;  // slots of this group that exist (>= 1)
+    if ((at & 1) == 0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        if (j0 + q < len) slots[at + q] = (unsigned short)(((w[q >> 1] >> (16 * (q & 1))) & 0xffffu) + (unsigned)shift);
+        for (int k = 0; k < 4; ++k) {
+            if (2 * k + 1 < left) *reinterpret_cast<unsigned *>(slots + at + 2 * k) = w[k];
+            else if (2 * k < left) slots[at + 2 * k] = (unsigned short)w[k];
+        }
+    } else {
+        slots[at] = (unsigned short)w[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // the pairs (1, 2), (3, 4), (5, 6) of the group
+            const unsigned pair = (w[k] >> 16) | (w[k + 1] << 16);
+            if (2 * k + 2 < left) *reinterpret_cast<unsigned *>(slots + at + 2 * k + 1) = pair;
+            else if (2 * k + 1 < left) slots[at + 2 * k + 1] = (unsigned short)pair;
+        }
+        if (7 < left) slots[at + 7] = (unsigned short)(w[3] >> 16);
+    }
 }
 
 // the rows of the block's FIRST pass of lane groups: up to two pattern groups per lane are loaded here (the caller lets

@@ -800,11 +800,11 @@ int csr_tune_placement(spmv_csr_dev *m) {
 // rows are short -- several rows per lane group, their patterns fetched pass after pass: 7-point 271 -> 285, 5-point
 // 186 -> 210 --, in fp32 (124 -> 133: the same LDS work for half the bytes) and for matrices that live in the Infinity
 // Cache (cant-size 10.8 -> 12.4).  The gain goes with the placement of the arrays: 1-2 % on a fast one, 9 % on a slow one.
-// Hence auto: fp64, streamed matrices (the `nt` threshold), 16 to 64 entries per row on average, tables of at most a
-// quarter of the slots.
+// Hence auto: fp64, matrices of more than twice the Infinity Cache (nlpkkt80-size, 29 M entries: 56.3 -> 58.4), 16 to 64
+// entries per row on average, tables of at most a quarter of the slots.
 int csr_build_patterns(spmv_csr_dev *m) {
     if (g_local_patterns == 0 || m->local_blocks <= 0 || !m->lcol || !m->ldesc4 || !m->row_ptr || m->M_local <= 0) return 0;
-    if (g_local_patterns < 0 && (m->value_bytes != 8 || m->nz * 10LL <= (128LL << 20) || m->nz < 16LL * m->M_local ||
+    if (g_local_patterns < 0 && (m->value_bytes != 8 || m->nz * 10LL <= (512LL << 20) || m->nz < 16LL * m->M_local ||
                                  m->nz > 64LL * m->M_local))
         return 0;
     UploadTrace trace("csr_build_patterns");

@@ -1276,9 +1276,9 @@ def test_pattern_plan_rebuilds_the_slots_bit_for_bit(gpu, oracle, dtype):
     assert info["pattern_slots"] * 4 <= rp[-1]                    # a stencil: the tables hold a fraction of the slots
     run(M, M, rp, col, val, True, True, row0=M // 3, row1=2 * M // 3)
     run(M, M, rp, col, val, False, False)                         # auto: a matrix of this size lives in the cache
-    if dtype == np.float64:                                       # auto keeps it: fp64, streamed, 28 per row
-        Mb, rpb, colb, valb = synth.kkt_like((64, 64, 66), 5)
-        assert rpb[-1] * 10 > (128 << 20)
+    if dtype == np.float64:                                       # auto keeps it: fp64, 28 per row, far beyond the cache
+        Mb, rpb, colb, valb = synth.kkt_like((104, 104, 106), 5)
+        assert rpb[-1] * 10 > (512 << 20)
         run(Mb, Mb, rpb, colb, valb, False, True)
     rp2, col2, val2 = banded_csr(rng, 20000, 20000, 22, 150)       # random columns inside a band: no two rows alike
     run(20000, 20000, rp2, col2, val2.astype(dtype), False, False)
