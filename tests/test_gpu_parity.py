@@ -1294,6 +1294,13 @@ def test_pattern_plan_rebuilds_the_slots_bit_for_bit(gpu, oracle, dtype):
     run(n, n, rp3, col3[order], val3, True, True)
 
 
+def test_pattern_plan_fuzz(gpu, oracle):
+    """tests/fuzz_patterns.py with a few dozen cases: random shapes through the forced pattern plan, bit for bit against
+    the slot stream and against the oracle within the gate."""
+    import fuzz_patterns
+    assert fuzz_patterns.run(40, 7, oracle) >= 20
+
+
 def test_power_iteration_halo_single_rank_communicator(gpu):
     """The RCCL side at world size 1: setup (all-gather of the needs record), an exchange with no peers, the
     all-reduce of the norm; the halo loop then gives the plain loop's result bit for bit."""
