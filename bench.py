@@ -787,7 +787,12 @@ def main():
                        "placement": {"val_address": hex(int(info.get("val_address", 0))),
                                      "placements_timed_at_upload": int(info.get("place_tries", 0)),
                                      "kernel_us_at_first_placement": round(float(info.get("place_first_us", 0.0)), 1),
-                                     "kernel_us_at_kept_placement": round(float(info.get("place_best_us", 0.0)), 1)}},
+                                     "kernel_us_at_kept_placement": round(float(info.get("place_best_us", 0.0)), 1)},
+                       # the x-window kernel's pattern plan (slots rebuilt from a table per block instead of read per
+                       # entry): built where the structure allows, kept where upload measured it faster on this handle
+                       "pattern_plan": {"slots_in_tables": int(info.get("pattern_slots", 0)),
+                                        "kernel_us_with": round(float(info.get("pattern_with_us", 0.0)), 1),
+                                        "kernel_us_without": round(float(info.get("pattern_without_us", 0.0)), 1)}},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,

@@ -113,6 +113,8 @@ typedef struct {
     long long pattern_slots; /* CSR: slots held by the pattern tables of an x-window plan (0: the kernel reads the 16-bit slot of
                                 every entry) -- where most rows of a block are their predecessor shifted by a constant the
                                 kernel rebuilds the slots from one table per block and 4 bytes per row ("local_patterns") */
+    float pattern_with_us;    /* (auto) what upload measured for its kernel with the pattern plan ... */
+    float pattern_without_us; /* ... and without (0 / 0: no plan was built); the plan stays where it is at least 2 % faster */
 } spmv_dev_info;
 
 /* ---- device ------------------------------------------------------------ */
@@ -169,8 +171,9 @@ int spmv_hip_gather_probe(int value_bytes, size_t table_bytes, int waves_per_cu,
  *                     "tile_min_pass" (256) a packed plan's windows with fewer entries than this, and fewer than one per
  *                     16 columns, go to the remainder kernel instead of being a pass (0: no remainder);
  *                     "local_patterns" -1 | 0 | 1 (read at upload and at launch) x-window plans: the kernel rebuilds a block's
- *                         slots from a pattern table instead of reading them -- auto: fp64 matrices of more than 512 MB with 16-64
- *                         entries per row whose tables hold at most a quarter of the slots (large stencils); 0 never; 1 always
+ *                         slots from a pattern table instead of reading them -- auto: built for streamed matrices of at least
+ *                         12 entries per row whose tables hold at most a quarter of the slots, then kept only if upload
+ *                         measures its kernel at least 2 % faster with it on this handle; 0 never; 1 always
  *                     "tile_mid_items" (0 = three rounds of the CUs) work items of the middle tier
  *                     "tile_expand" -1 | 0 | 1 (read at upload and at launch) a tile plan with gather passes runs on an
  *                         expanded x -- auto: from 2^22 entries on when under a tenth of them are staged, fp32 always, fp64

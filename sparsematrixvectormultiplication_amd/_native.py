@@ -58,7 +58,7 @@ class DevInfo(C.Structure):
                 ("tile_mid_rows", C.c_int), ("tile_mid_items", C.c_int), ("tile_mid_entries", C.c_longlong),
                 ("place_tries", C.c_int), ("place_first_us", C.c_float), ("place_best_us", C.c_float),
                 ("val_address", C.c_ulonglong), ("tile_expanded_entries", C.c_longlong),
-                ("pattern_slots", C.c_longlong)]
+                ("pattern_slots", C.c_longlong), ("pattern_with_us", C.c_float), ("pattern_without_us", C.c_float)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -800,13 +800,14 @@ int csr_tune_placement(spmv_csr_dev *m) {
 // rows are short -- several rows per lane group, their patterns fetched pass after pass: 7-point 271 -> 285, 5-point
 // 186 -> 210 --, in fp32 (124 -> 133: the same LDS work for half the bytes) and for matrices that live in the Infinity
 // Cache (cant-size 10.8 -> 12.4).  The gain goes with the placement of the arrays: 1-2 % on a fast one, 9 % on a slow one.
-// Hence auto: fp64, matrices of more than twice the Infinity Cache (nlpkkt80-size, 29 M entries: 56.3 -> 58.4), 16 to 64
-// entries per row on average, tables of at most a quarter of the slots.
+// (nlpkkt80-size, 29 M entries: 56.3 -> 58.4.)  And even where it gains the gain goes with the placement of the arrays
+// (27-point stencil: 204 -> 195 on one box, 177 -> 183 on another).  Hence auto: streamed matrices (the `nt` threshold)
+// of at least 12 entries per row whose tables hold at most a quarter of the slots get a plan BUILT, and upload then
+// times its own kernel with and without it and keeps the plan only if it is at least 2 % faster on this handle
+// (csr_tune_patterns, beside the placement search).
 int csr_build_patterns(spmv_csr_dev *m) {
     if (g_local_patterns == 0 || m->local_blocks <= 0 || !m->lcol || !m->ldesc4 || !m->row_ptr || m->M_local <= 0) return 0;
-    if (g_local_patterns < 0 && (m->value_bytes != 8 || m->nz * 10LL <= (512LL << 20) || m->nz < 16LL * m->M_local ||
-                                 m->nz > 64LL * m->M_local))
-        return 0;
+    if (g_local_patterns < 0 && (m->nz * (m->value_bytes + 2LL) <= (128LL << 20) || m->nz < 12LL * m->M_local)) return 0;
     UploadTrace trace("csr_build_patterns");
     const int B = m->local_blocks;
     int *rowflag = nullptr, *pcount = nullptr;
@@ -873,6 +874,54 @@ int csr_build_patterns(spmv_csr_dev *m) {
     m->pat_max = widest;
     m->device_bytes += ((size_t)total + 1024) * 2 + (size_t)m->M_local * 4 + (size_t)B * 8;
     trace.mark("tables");
+    return 0;
+}
+
+// (auto) the handle's kernel with and without its pattern plan, alternately, two rounds of 2 + 6 launches each: the plan
+// stays if it is at least 2 % faster here.  Never a reason to lose the handle.
+int csr_tune_patterns(spmv_csr_dev *m) {
+    if (g_local_patterns >= 0 || !m->ptab || !m->x || !m->y) return 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return 0;
+    }
+    auto measure = [&](int patterns, float &us) {
+        const int keep = g_local_patterns;
+        g_local_patterns = patterns;
+        int rc = 0;
+        for (int i = 0; i < 2 && !rc; ++i) rc = csr_launch_any(m, SPMV_CSR_AUTO, m->x, m->y, g_stream);
+        hipError_t e = rc ? hipErrorUnknown : hipEventRecord(e0, g_stream);
+        for (int i = 0; i < 6 && e == hipSuccess && !rc; ++i) rc = csr_launch_any(m, SPMV_CSR_AUTO, m->x, m->y, g_stream);
+        if (e == hipSuccess && !rc) e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess && !rc) e = hipEventElapsedTime(&ms, e0, e1);
+        g_local_patterns = keep;
+        us = ms * 1e3f / 6.0f;
+        return (e == hipSuccess && !rc) ? 0 : -1;
+    };
+    float with_us = 0, without_us = 0;
+    bool ok = true;
+    for (int round = 0; round < 2 && ok; ++round) {
+        float a = 0, b = 0;
+        ok = measure(1, a) == 0 && measure(0, b) == 0;
+        with_us = round ? std::min(with_us, a) : a;
+        without_us = round ? std::min(without_us, b) : b;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    m->pat_with_us = with_us;
+    m->pat_without_us = without_us;
+    if (!ok || with_us > 0.98f * without_us) {  // not faster here: the slot stream stays
+        (void)hipFree(m->ptab);
+        (void)hipFree(m->rinfo);
+        (void)hipFree(m->pdesc);
+        m->ptab = nullptr;
+        m->rinfo = nullptr;
+        m->pdesc = nullptr;
+        m->pat_slots = 0;
+    }
     return 0;
 }
 
@@ -1135,6 +1184,7 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     if (!have_local && !tb.have_tiles && nz < (20LL << 20) && max_row <= std::max(64.0, 8.0 * mean))
         m->auto_variant = SPMV_CSR_SUBWAVE;
     trace.mark("blocks, remaining uploads, vectors");
+    (void)csr_tune_patterns(m);      // (auto) the pattern plan stays only where it measures faster on this handle
     (void)csr_tune_placement<T>(m);  // (never a reason to lose the handle: whatever went wrong in there, it holds a valid array)
     trace.mark("placement tuning");
     *out = m;
@@ -1851,6 +1901,8 @@ extern "C" int spmv_hip_csr_info(const spmv_csr_dev *m, spmv_dev_info *out) {
     out->val_address = (unsigned long long)(uintptr_t)m->val;
     out->tile_expanded_entries = m->xe && m->expansion ? (long long)m->expansion->entries : 0;
     out->pattern_slots = m->ptab ? m->pat_slots : 0;
+    out->pattern_with_us = m->pat_with_us;
+    out->pattern_without_us = m->pat_without_us;
     out->stream_kernel = m->local_blocks > 0 ? 1 : m->tile_blocks > 0 ? 3
                          : ((m->stream_cap == 4096 || m->stream_cap == 2048) && m->M_local > 0 &&
                             m->nz < (long long)m->M_local * (m->stream_cap / kBlock)) ? 2 : 0;

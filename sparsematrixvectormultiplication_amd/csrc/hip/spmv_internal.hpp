@@ -200,7 +200,8 @@ struct spmv_csr_dev {
     unsigned *rinfo = nullptr;        // [M_local] start of the row's pattern in its block's table | shift << 16
     int2 *pdesc = nullptr;            // [local_blocks] {first element in ptab (even), elements}
     long long pat_slots = 0;          // elements of all tables
-    int pat_max = 0;                  // the largest table (elements): LDS for it
+    int pat_max = 0;                  // the largest table (elements)
+    float pat_with_us = 0, pat_without_us = 0;  // (auto) the kernel with / without the plan, timed at upload (csr_tune_patterns)
     int local_blocks = 0;             // 0: no plan (not profitable / not possible)
     int local_stage_lines = 0;        // LDS stage: most lines any block lists, in steps of 32
     int local_cap = 2048;

@@ -1257,7 +1257,8 @@ def test_pattern_plan_rebuilds_the_slots_bit_for_bit(gpu, oracle, dtype):
             with sp.CsrDevice(M, N, rp, col, val, row0=row0, row1=M if row1 is None else row1) as dev:
                 info = dev.info()
                 assert info["local_blocks"] > 0
-                assert (info["pattern_slots"] > 0) == expect_plan, info["pattern_slots"]
+                if expect_plan is not None:
+                    assert (info["pattern_slots"] > 0) == expect_plan, info["pattern_slots"]
                 lo, hi = row0, M if row1 is None else row1
                 sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * x.itemsize)
                 y = dev.spmv(x, sp.CSR_STREAM)[lo:hi].copy()
@@ -1276,10 +1277,12 @@ def test_pattern_plan_rebuilds_the_slots_bit_for_bit(gpu, oracle, dtype):
     assert info["pattern_slots"] * 4 <= rp[-1]                    # a stencil: the tables hold a fraction of the slots
     run(M, M, rp, col, val, True, True, row0=M // 3, row1=2 * M // 3)
     run(M, M, rp, col, val, False, False)                         # auto: a matrix of this size lives in the cache
-    if dtype == np.float64:                                       # auto keeps it: fp64, 28 per row, far beyond the cache
-        Mb, rpb, colb, valb = synth.kkt_like((104, 104, 106), 5)
-        assert rpb[-1] * 10 > (512 << 20)
-        run(Mb, Mb, rpb, colb, valb, False, True)
+    if dtype == np.float64:                                       # auto: built (streamed, 28 per row), then kept or not by
+        Mb, rpb, colb, valb = synth.kkt_like((64, 64, 66), 5)     # upload's own measurement -- either way the same bits
+        assert rpb[-1] * 10 > (128 << 20)
+        info = run(Mb, Mb, rpb, colb, valb, False, None)
+        assert info["pattern_with_us"] > 0 and info["pattern_without_us"] > 0
+        assert (info["pattern_slots"] > 0) == (info["pattern_with_us"] <= 0.98 * info["pattern_without_us"])
     rp2, col2, val2 = banded_csr(rng, 20000, 20000, 22, 150)       # random columns inside a band: no two rows alike
     run(20000, 20000, rp2, col2, val2.astype(dtype), False, False)
     run(20000, 20000, rp2, col2, val2.astype(dtype), True, True)
