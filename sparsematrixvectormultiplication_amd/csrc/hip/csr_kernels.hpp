@@ -469,10 +469,23 @@ struct pat_ctx {
     unsigned short *slots;          // LDS [CAP + 8]: the block's slots, entry order, from `base` on
     const uint4 *ptab8;             // the block's pattern table in memory, groups of 8 slots (a row's pattern starts at a group)
     const unsigned *rinfo;          // per row: first group of its pattern in the block's table | shift << 16
-    const int *row_ptr;
-    int r0, nrows, base, first, end, lanes, seg_lo, seg_hi;
+    const int *row_ptr;             // CSR: the rows' extents ...
+    const unsigned *row_seg;        // ... HLL (hll_lds_local): first slot in the window | slots << 16 per row (base = 0 then)
+    int r0, nrows, base, first, end, lanes, seg_lo, seg_hi;  // seg_lo / seg_hi: the first row's extent, RAW (CSR: two row_ptr
+                                    // values; HLL: its row_seg word in seg_lo) -- decoded where it is used, behind the stream
     unsigned ri;                    // rinfo of this lane group's first row
 };
+// a row's first slot (as the slots array counts: from `base`) and its length, out of the raw extent
+template <bool HLL>
+__device__ __forceinline__ void pat_row_extent(const pat_ctx &c, int raw_lo, int raw_hi, int &lo, int &len) {
+    if constexpr (HLL) {
+        lo = (int)((unsigned)raw_lo & 0xffffu);
+        len = (int)((unsigned)raw_lo >> 16);
+    } else {
+        lo = raw_lo - c.base;
+        len = raw_hi - raw_lo;
+    }
+}
 
 // slots[at .. at + 8) (those below len) = the pattern group + shift.  Written as PAIRS wherever a pair lies on a 4-byte
 // boundary of the LDS array (a row starts at an even or an odd entry of its block): four or five LDS writes per group
@@ -506,8 +519,11 @@ __device__ __forceinline__ void pat_write_group(unsigned short *slots, int at, i
 
 // the rows of the block's FIRST pass of lane groups: up to two pattern groups per lane are loaded here (the caller lets
 // them queue behind the value stream) ...
+template <bool HLL = false>
 __device__ __forceinline__ void pat_load_first(const pat_ctx c, uint4 (&p)[2]) {
-    const int my_lane = threadIdx.x % c.lanes, len = c.seg_hi - c.seg_lo, off8 = (int)(c.ri & 0xffffu);
+    int lo, len;
+    pat_row_extent<HLL>(c, c.seg_lo, c.seg_hi, lo, len);
+    const int my_lane = threadIdx.x % c.lanes, off8 = (int)(c.ri & 0xffffu);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int g = my_lane + k * c.lanes;
@@ -516,30 +532,38 @@ __device__ __forceinline__ void pat_load_first(const pat_ctx c, uint4 (&p)[2]) {
 }
 // ... and written here, with whatever is left: longer rows, further passes of rows (blocks of very short rows), and zeros
 // for the halves of the lanes' pairs that lie outside the block (in front of its first entry, behind its last)
-template <int BLOCK, int CAP>
+template <int BLOCK, int CAP, bool HLL = false>
 __device__ __forceinline__ void pat_expand_slots(const pat_ctx c, const uint4 (&p)[2]) {
     const int t = threadIdx.x;
     const int my_row = t / c.lanes, my_lane = t % c.lanes, rows_per_pass = BLOCK / c.lanes;
-    int lo = c.seg_lo, hi = c.seg_hi;
+    int raw_lo = c.seg_lo, raw_hi = c.seg_hi;
     unsigned ri = c.ri;
     for (int first = 0; first < c.nrows; first += rows_per_pass) {  // all lanes stay in the loop
         const int row = first + my_row;
         if (first > 0) {
-            lo = hi = 0;
+            raw_lo = raw_hi = 0;
+            ri = 0;
             if (row < c.nrows) {
-                lo = c.row_ptr[c.r0 + row];
-                hi = c.row_ptr[c.r0 + row + 1];
+                if constexpr (HLL) {
+                    raw_lo = (int)c.row_seg[c.r0 + row];
+                } else {
+                    raw_lo = c.row_ptr[c.r0 + row];
+                    raw_hi = c.row_ptr[c.r0 + row + 1];
+                }
                 ri = c.rinfo[c.r0 + row];
             }
         }
-        const int off8 = (int)(ri & 0xffffu), shift = (int)(short)(ri >> 16), len = hi - lo;
+        int lo, len;
+        pat_row_extent<HLL>(c, raw_lo, raw_hi, lo, len);
+        if (first > 0 && row >= c.nrows) len = 0;
+        const int off8 = (int)(ri & 0xffffu), shift = (int)(short)(ri >> 16);
         int g = my_lane;
         if (first == 0) {
 #pragma unroll
             for (int k = 0; k < 2; ++k, g += c.lanes)
-                if (g * 8 < len) pat_write_group(c.slots, lo - c.base + g * 8, g * 8, len, p[k], shift);
+                if (g * 8 < len) pat_write_group(c.slots, lo + g * 8, g * 8, len, p[k], shift);
         }
-        for (; g * 8 < len; g += c.lanes) pat_write_group(c.slots, lo - c.base + g * 8, g * 8, len, c.ptab8[off8 + g], shift);
+        for (; g * 8 < len; g += c.lanes) pat_write_group(c.slots, lo + g * 8, g * 8, len, c.ptab8[off8 + g], shift);
     }
     constexpr int kUnit = 2 * BLOCK;
 #pragma unroll
@@ -550,7 +574,7 @@ __device__ __forceinline__ void pat_expand_slots(const pat_ctx c, const uint4 (&
     }
 }
 
-template <typename T, bool NT, int CAP, int ROUNDS>
+template <typename T, bool NT, int CAP, int ROUNDS, bool HLL = false>
 __device__ __forceinline__ void local_stage_full_pat(T *stage, const int *__restrict__ my_lines, int last_line,
                                                      const T *__restrict__ val, const T *__restrict__ x, int e_first,
                                                      const pat_ctx pc) {
@@ -570,7 +594,7 @@ __device__ __forceinline__ void local_stage_full_pat(T *stage, const int *__rest
     // behind the stream: the rows' pattern groups (their addresses came with the row extents, ahead of the stream),
     // then the x lines
     uint4 pg[2];
-    pat_load_first(pc, pg);
+    pat_load_first<HLL>(pc, pg);
     uint4 xl[ROUNDS];
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k) {
@@ -578,7 +602,7 @@ __device__ __forceinline__ void local_stage_full_pat(T *stage, const int *__rest
         xl[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
     }
     __builtin_amdgcn_sched_barrier(0);
-    pat_expand_slots<kBlock, CAP>(pc, pg);
+    pat_expand_slots<kBlock, CAP, HLL>(pc, pg);
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k)
         *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) = xl[k];
@@ -652,6 +676,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream_local(int num_blocks, int x
         pc.ptab8 = reinterpret_cast<const uint4 *>(ptab + pd.x);
         pc.rinfo = rinfo;
         pc.row_ptr = row_ptr;
+        pc.row_seg = nullptr;
         pc.r0 = r0;
         pc.nrows = nrows;
         pc.base = base;

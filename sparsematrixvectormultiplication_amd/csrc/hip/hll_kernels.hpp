@@ -266,7 +266,10 @@ __global__ __launch_bounds__(kBlock) void hll_lds(int stage_slots, const int4 *_
 // csr_stream_local (see csr_kernels.hpp for the reasoning and the line-list format).  Windows
 // are cut at upload with both limits (kLocalCap slots, kLocalLinesMax lines); padding slots
 // repeat the row's last column, so they add no lines.
-template <typename T, bool NT, int CAP>
+// PAT (round 3): a pattern plan (csr_kernels.hpp, "slot PATTERNS") -- lja is not read; the slots of a window are rebuilt
+// in LDS from its pattern table: in a slab every row of a hack has the hack's length, padding included (a padding slot
+// repeats the row's last column: part of the pattern), so every row but a window's first can be its predecessor shifted.
+template <typename T, bool NT, int CAP, bool PAT = false>
 __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_chunk,
                                                         const int4 *__restrict__ desc,
                                                         const int4 *__restrict__ ldesc,
@@ -274,7 +277,10 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
                                                         const unsigned *__restrict__ row_seg,
                                                         const unsigned short *__restrict__ lja,
                                                         const T *__restrict__ AS,
-                                                        const T *__restrict__ x, T *__restrict__ y) {
+                                                        const T *__restrict__ x, T *__restrict__ y,
+                                                        const int2 *__restrict__ pdesc = nullptr,
+                                                        const unsigned *__restrict__ rinfo = nullptr,
+                                                        const unsigned short *__restrict__ ptab = nullptr, int stage_bytes = 0) {
         using V2 = typename vec2<T>::type;
     constexpr int kUnit = 2 * kBlock, kUnits = CAP / kUnit;
     extern __shared__ __align__(16) unsigned char hll_local_lds[];
@@ -312,7 +318,61 @@ __global__ __launch_bounds__(kBlock) void hll_lds_local(int num_blocks, int xcd_
     const int *my_lines = lines + ld.x;
     const unsigned short *wj = lja + base;
     const T *wa = AS + base;
-    if (units == kUnits) {
+    if constexpr (PAT) {
+        const int2 pd = pdesc[b];
+        pat_ctx pc;
+        pc.slots = reinterpret_cast<unsigned short *>(hll_local_lds + stage_bytes);
+        pc.ptab8 = reinterpret_cast<const uint4 *>(ptab + pd.x);
+        pc.rinfo = rinfo;
+        pc.row_ptr = nullptr;
+        pc.row_seg = row_seg;
+        pc.r0 = row_first;
+        pc.nrows = nrows;
+        pc.base = 0;
+        pc.first = (int)(first_slot - base);
+        pc.end = count;
+        pc.lanes = lanes;
+        pc.seg_lo = (int)seg0;  // (raw: decoded behind the stream)
+        pc.seg_hi = 0;
+        pc.ri = my_row < nrows ? rinfo[row_first + my_row] : 0u;
+        if (units == kUnits) {
+            switch (rounds) {
+                case 1: local_stage_full_pat<T, NT, CAP, 1, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+                case 2: local_stage_full_pat<T, NT, CAP, 2, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+                case 3: local_stage_full_pat<T, NT, CAP, 3, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+                case 4: local_stage_full_pat<T, NT, CAP, 4, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+                case 5: local_stage_full_pat<T, NT, CAP, 5, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+                case 6: local_stage_full_pat<T, NT, CAP, 6, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+                case 7: local_stage_full_pat<T, NT, CAP, 7, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+                default: local_stage_full_pat<T, NT, CAP, 8, true>(stage, my_lines, ld.y - 1, wa, x, 2 * t, pc); break;
+            }
+        } else {
+            for (int k = 0; k < rounds; ++k) {
+                const int line = my_lines[min(k * kLocalLineQuantum + (t >> 3), ld.y - 1)];
+                const unsigned off = (unsigned)line * (unsigned)kLineBytes + (unsigned)(t & 7) * 16u;
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(stage) + (k * kBlock + t) * 16) =
+                    *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(x) + off);
+            }
+            uint4 pg[2];
+            pat_load_first<true>(pc, pg);
+            pat_expand_slots<kBlock, CAP, true>(pc, pg);
+            __syncthreads();
+            V2 p[kUnits];
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u) {
+                if (u < units) {
+                    const unsigned c = *reinterpret_cast<const unsigned *>(pc.slots + u * kUnit + 2 * t);
+                    p[u] = stream_load<NT>(reinterpret_cast<const V2 *>(wa + 2 * t + u * kUnit));
+                    p[u].x *= stage[c & 0xffffu];
+                    p[u].y *= stage[c >> 16];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u)
+                if (u < units) *reinterpret_cast<V2 *>(&stage[u * kUnit + 2 * t]) = p[u];
+        }
+    } else if (units == kUnits) {
         switch (rounds) {
             case 1: local_stage_full<T, NT, CAP, 1>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;
             case 2: local_stage_full<T, NT, CAP, 2>(stage, my_lines, ld.y - 1, wj, wa, x, 2 * t); break;

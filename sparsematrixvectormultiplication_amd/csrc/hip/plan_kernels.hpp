@@ -124,24 +124,50 @@ __global__ __launch_bounds__(kBlock) void plan_fill(int segments, const long lon
 // ---- the pattern plan of an x-window plan (csr_stream_local<.., PAT>): one workgroup per block.
 // pat_mark: rowflag[r] = 0x10000 | (delta & 0xffff) when row r's slots are the previous row's (same block, same length)
 // plus the constant delta, else 0 (its slots go into the block's pattern table); pcount[b] = slots in that table (even).
-template <int BLOCK>
+// HLL = false: desc = {first row, first entry, rows, end entry}, a row's slots are slot[row_ptr[r] .. row_ptr[r + 1]);
+// HLL = true (hll_lds_local's windows): desc = {first row, rows, first slot lo, hi}, a row's slots are
+// slot[base + (row_seg[r] & 0xffff) .. + (row_seg[r] >> 16)) with base = the window's even base
+template <bool HLL>
+__device__ __forceinline__ void pat_block_rows(const int4 d, int &r0, int &nrows, long long &base) {
+    r0 = d.x;
+    nrows = HLL ? d.y : d.z;
+    base = HLL ? ((((long long)d.w << 32) | (unsigned)d.z) & ~1LL) : 0;
+}
+template <bool HLL>
+__device__ __forceinline__ void pat_row_slots(const int *__restrict__ row_ptr, const unsigned *__restrict__ row_seg, long long base,
+                                              int r, long long &s, int &len) {
+    if constexpr (HLL) {
+        const unsigned seg = row_seg[r];
+        s = base + (long long)(seg & 0xffffu);
+        len = (int)(seg >> 16);
+    } else {
+        s = row_ptr[r];
+        len = row_ptr[r + 1] - row_ptr[r];
+    }
+}
+template <int BLOCK, bool HLL = false>
 __global__ __launch_bounds__(BLOCK) void pat_mark(int blocks, const int4 *__restrict__ desc, const int *__restrict__ row_ptr,
                                                   const unsigned short *__restrict__ slot, int *__restrict__ rowflag,
-                                                  int *__restrict__ pcount) {
+                                                  int *__restrict__ pcount, const unsigned *__restrict__ row_seg = nullptr) {
     __shared__ int cnt;
     const int b = blockIdx.x, t = threadIdx.x;
     if (b >= blocks) return;
-    const int4 d = desc[b];
-    const int r0 = d.x, nrows = d.z;
+    int r0, nrows;
+    long long base;
+    pat_block_rows<HLL>(desc[b], r0, nrows, base);
     if (t == 0) cnt = 0;
     __syncthreads();
     for (int i = t; i < nrows; i += BLOCK) {
-        const int s = row_ptr[r0 + i], len = row_ptr[r0 + i + 1] - s;
+        long long s;
+        int len;
+        pat_row_slots<HLL>(row_ptr, row_seg, base, r0 + i, s, len);
         bool derived = false;
         int delta = 0;
         if (i > 0 && len > 0) {
-            const int ps = row_ptr[r0 + i - 1];
-            if (s - ps == len) {
+            long long ps;
+            int plen;
+            pat_row_slots<HLL>(row_ptr, row_seg, base, r0 + i - 1, ps, plen);
+            if (plen == len) {
                 delta = (int)slot[s] - (int)slot[ps];
                 derived = true;
                 for (int j = 1; j < len; ++j)
@@ -160,15 +186,17 @@ __global__ __launch_bounds__(BLOCK) void pat_mark(int blocks, const int4 *__rest
 // pat_fill: rinfo[r] = the group of 8 slots at which the row's pattern starts in the block's table | shift << 16 (a row that is its predecessor
 // shifted shares the predecessor's pattern, its shift the sum of the deltas since); the table itself; pdesc[b] = {first
 // element in ptab, elements}
-template <int BLOCK>
+template <int BLOCK, bool HLL = false>
 __global__ __launch_bounds__(BLOCK) void pat_fill(int blocks, const int4 *__restrict__ desc, const int *__restrict__ row_ptr,
                                                   const unsigned short *__restrict__ slot, const int *__restrict__ rowflag,
                                                   const long long *__restrict__ pbase, unsigned *__restrict__ rinfo,
-                                                  unsigned short *__restrict__ ptab, int2 *__restrict__ pdesc) {
+                                                  unsigned short *__restrict__ ptab, int2 *__restrict__ pdesc,
+                                                  const unsigned *__restrict__ row_seg = nullptr) {
     const int b = blockIdx.x, t = threadIdx.x;
     if (b >= blocks) return;
-    const int4 d = desc[b];
-    const int r0 = d.x, nrows = d.z;
+    int r0, nrows;
+    long long base;
+    pat_block_rows<HLL>(desc[b], r0, nrows, base);
     const long long pb = pbase[b];
     if (t == 0) {
         int filled = 0, cur = 0, shift = 0;
@@ -177,9 +205,12 @@ __global__ __launch_bounds__(BLOCK) void pat_fill(int blocks, const int4 *__rest
             if (f & 0x10000) {
                 shift += (int)(short)(f & 0xffff);
             } else {
+                long long s;
+                int len;
+                pat_row_slots<HLL>(row_ptr, row_seg, base, r0 + i, s, len);
                 cur = filled;  // (in groups of 8 slots)
                 shift = 0;
-                filled += (row_ptr[r0 + i + 1] - row_ptr[r0 + i] + 7) >> 3;
+                filled += (len + 7) >> 3;
             }
             rinfo[r0 + i] = (unsigned)cur | ((unsigned)(shift & 0xffff) << 16);
         }
@@ -188,7 +219,9 @@ __global__ __launch_bounds__(BLOCK) void pat_fill(int blocks, const int4 *__rest
     __syncthreads();
     for (int i = t; i < nrows; i += BLOCK) {
         if (rowflag[r0 + i] & 0x10000) continue;
-        const int s = row_ptr[r0 + i], len = row_ptr[r0 + i + 1] - s;
+        long long s;
+        int len;
+        pat_row_slots<HLL>(row_ptr, row_seg, base, r0 + i, s, len);
         const long long o = pb + 8 * (long long)(rinfo[r0 + i] & 0xffffu);
         for (int j = 0; j < len; ++j) ptab[o + j] = slot[s + j];
     }

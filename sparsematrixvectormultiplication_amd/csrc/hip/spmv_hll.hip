@@ -266,6 +266,120 @@ int hll_finish_handle(spmv_hll_dev *m, int total_rows, int N, const std::vector<
 
 }  // namespace
 
+// The HLL twins of csr_build_patterns / csr_tune_patterns (spmv_csr.hip): the windows' pattern plan, built on the device
+// from the plan's own arrays for streamed slabs of at least 12 slots per row whose tables hold at most a quarter of the
+// slots, and kept only where upload times its own kernel at least 2 % faster with it.
+static int hll_build_patterns(spmv_hll_dev *m) {
+    if (g_local_patterns == 0 || m->local_blocks <= 0 || !m->lja || !m->ldesc4 || !m->row_seg || m->M <= 0) return 0;
+    if (g_local_patterns < 0 && (m->slots * 10LL <= (128LL << 20) || m->slots < 12LL * m->M)) return 0;
+    const int B = m->local_blocks;
+    int *rowflag = nullptr, *pcount = nullptr;
+    long long *pbase = nullptr;
+    auto drop_tmp = [&] {
+        (void)hipFree(rowflag);
+        (void)hipFree(pcount);
+        (void)hipFree(pbase);
+    };
+    hipError_t e = hipMalloc((void **)&rowflag, (size_t)m->M * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&pcount, (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&pbase, (size_t)B * sizeof(long long));
+    if (e == hipSuccess) e = hipMemsetAsync(rowflag, 0, (size_t)m->M * sizeof(int), g_stream);
+    if (e != hipSuccess) {
+        drop_tmp();
+        return fail("pattern plan: allocation failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((pat_mark<256, true>), dim3(B), dim3(256), 0, g_stream, B, m->ldesc4, (const int *)nullptr, m->lja, rowflag,
+                       pcount, m->row_seg);
+    std::vector<int> h_count((size_t)B);
+    e = hipMemcpyAsync(h_count.data(), pcount, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) {
+        drop_tmp();
+        return fail("pattern plan: marking the rows failed: %s", hipGetErrorString(e));
+    }
+    std::vector<long long> h_base((size_t)B);
+    long long total = 0;
+    for (int b = 0; b < B; ++b) {
+        h_base[(size_t)b] = total;
+        total += h_count[(size_t)b];
+    }
+    if ((g_local_patterns < 0 && total * 4 > m->slots) || total > 0x7ffffff0LL) {
+        drop_tmp();
+        return 0;
+    }
+    e = hipMalloc((void **)&m->ptab, ((size_t)total + 1024) * sizeof(unsigned short));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->rinfo, (size_t)m->M * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->pdesc, (size_t)B * sizeof(int2));
+    if (e == hipSuccess) e = hipMemsetAsync(m->ptab, 0, ((size_t)total + 1024) * sizeof(unsigned short), g_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->rinfo, 0, (size_t)m->M * sizeof(unsigned), g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pbase, h_base.data(), (size_t)B * sizeof(long long), hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((pat_fill<256, true>), dim3(B), dim3(256), 0, g_stream, B, m->ldesc4, (const int *)nullptr, m->lja, rowflag,
+                           pbase, m->rinfo, m->ptab, m->pdesc, m->row_seg);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    drop_tmp();
+    if (e != hipSuccess) {
+        (void)hipFree(m->ptab);
+        (void)hipFree(m->rinfo);
+        (void)hipFree(m->pdesc);
+        m->ptab = nullptr;
+        m->rinfo = nullptr;
+        m->pdesc = nullptr;
+        return fail("pattern plan: building the tables failed: %s", hipGetErrorString(e));
+    }
+    m->pat_slots = total;
+    m->device_bytes += ((size_t)total + 1024) * 2 + (size_t)m->M * 4 + (size_t)B * 8;
+    return 0;
+}
+
+static void hll_tune_patterns(spmv_hll_dev *m) {
+    if (g_local_patterns >= 0 || !m->ptab || !m->x || !m->y) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return;
+    }
+    auto measure = [&](int patterns, float &us) {
+        const int keep = g_local_patterns;
+        g_local_patterns = patterns;
+        int rc = 0;
+        for (int i = 0; i < 2 && !rc; ++i) rc = hll_launch(m, SPMV_HLL_AUTO, m->x, m->y, g_stream);
+        hipError_t e = rc ? hipErrorUnknown : hipEventRecord(e0, g_stream);
+        for (int i = 0; i < 6 && e == hipSuccess && !rc; ++i) rc = hll_launch(m, SPMV_HLL_AUTO, m->x, m->y, g_stream);
+        if (e == hipSuccess && !rc) e = hipEventRecord(e1, g_stream);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(g_stream);
+        float ms = 0;
+        if (e == hipSuccess && !rc) e = hipEventElapsedTime(&ms, e0, e1);
+        g_local_patterns = keep;
+        us = ms * 1e3f / 6.0f;
+        return (e == hipSuccess && !rc) ? 0 : -1;
+    };
+    float with_us = 0, without_us = 0;
+    bool ok = true;
+    for (int round = 0; round < 2 && ok; ++round) {
+        float a = 0, b = 0;
+        ok = measure(1, a) == 0 && measure(0, b) == 0;
+        with_us = round ? std::min(with_us, a) : a;
+        without_us = round ? std::min(without_us, b) : b;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    m->pat_with_us = with_us;
+    m->pat_without_us = without_us;
+    if (!ok || with_us > 0.98f * without_us) {
+        (void)hipFree(m->ptab);
+        (void)hipFree(m->rinfo);
+        (void)hipFree(m->pdesc);
+        m->ptab = nullptr;
+        m->rinfo = nullptr;
+        m->pdesc = nullptr;
+        m->pat_slots = 0;
+    }
+}
+
 // The HLL twin of csr_tune_placement (spmv_csr.hip): a slab whose AS array is large enough for its placement to
 // matter times its own kernel on a few fresh allocations of AS and keeps the fastest.
 static void hll_tune_placement(spmv_hll_dev *m) {
@@ -552,6 +666,7 @@ static int spmv_hip_hll_upload_part_body(const HLLMatrix *hll, int total_rows, i
         spmv_hip_hll_free(m);
         return -1;
     }
+    if (hll_build_patterns(m) == 0) hll_tune_patterns(m);  // (never a reason to lose the handle)
     hll_tune_placement(m);
     *out = m;
     return 0;
@@ -643,6 +758,7 @@ static int spmv_hip_hll_from_csr_body(const spmv_csr_dev *csr, spmv_hll_dev **ou
         spmv_hip_hll_free(m);
         return -1;
     }
+    if (hll_build_patterns(m) == 0) hll_tune_patterns(m);  // (never a reason to lose the handle)
     hll_tune_placement(m);
     *out = m;
     return 0;
@@ -680,6 +796,9 @@ extern "C" void spmv_hip_hll_free(spmv_hll_dev *m) {
     (void)hipFree(m->lines);
     (void)hipFree(m->lja);
     (void)hipFree(m->row_seg);
+    (void)hipFree(m->ptab);
+    (void)hipFree(m->rinfo);
+    (void)hipFree(m->pdesc);
     spmv_hip_csr_free(m->tiles);
     (void)hipFree(m->x);
     (void)hipFree(m->y);
@@ -717,6 +836,9 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     out->place_first_us = m->place_first_us;
     out->place_best_us = m->place_best_us;
     out->val_address = (unsigned long long)(uintptr_t)m->AS;
+    out->pattern_slots = m->ptab ? m->pat_slots : 0;
+    out->pattern_with_us = m->pat_with_us;
+    out->pattern_without_us = m->pat_without_us;
     out->stream_kernel = m->local_blocks > 0 ? 1 : m->tiles ? 2 : 0;
     if (m->tiles) {
         spmv_dev_info t;
@@ -735,9 +857,9 @@ extern "C" int spmv_hip_hll_info(const spmv_hll_dev *m, spmv_dev_info *out) {
     }
     out->local_stage_lines = m->local_stage_lines;
     out->local_lines = m->local_lines;
-    if (m->local_blocks > 0)
-        out->stream_bytes = m->slots * 10 + 4 * m->local_lines + 32LL * m->local_blocks + 12LL * m->hacks +
-                            8LL * ((long long)m->M + m->N);
+    if (m->local_blocks > 0)  // (a pattern plan: the tables and 4 bytes per row instead of 2 bytes per slot)
+        out->stream_bytes = m->slots * 8 + (m->ptab ? 2 * m->pat_slots + 4LL * m->M + 8LL * m->local_blocks : 2 * m->slots) +
+                            4 * m->local_lines + 32LL * m->local_blocks + 12LL * m->hacks + 8LL * ((long long)m->M + m->N);
     return 0;
 }
 
@@ -796,7 +918,18 @@ int hll_launch(const spmv_hll_dev *m, int variant, const double *x, double *y_fu
                 const int lgrid = (m->local_blocks + 8 * lchunk - 1) / (8 * lchunk) * (8 * lchunk);
                 const size_t llds = std::max((size_t)2048 * sizeof(double), (size_t)m->local_stage_lines * kLineBytes);
                 const bool lnt = g_local_nt < 0 ? m->slots * 10 > (128LL << 20) : g_local_nt != 0;
-                if (lnt)
+                // a pattern plan: the windows' slots are rebuilt in LDS (behind the stage), lja is not read
+                const bool patterns = m->ptab && m->rinfo && m->pdesc && g_local_patterns != 0;
+                const size_t pat_lds = llds + ((size_t)2048 + 8) * sizeof(unsigned short);
+                if (patterns && lnt)
+                    hipLaunchKernelGGL((hll_lds_local<double, true, 2048, true>), dim3(lgrid), dim3(kBlock), pat_lds, s,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_seg,
+                                       m->lja, m->AS, x, y, m->pdesc, m->rinfo, m->ptab, (int)llds);
+                else if (patterns)
+                    hipLaunchKernelGGL((hll_lds_local<double, false, 2048, true>), dim3(lgrid), dim3(kBlock), pat_lds, s,
+                                       m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_seg,
+                                       m->lja, m->AS, x, y, m->pdesc, m->rinfo, m->ptab, (int)llds);
+                else if (lnt)
                     hipLaunchKernelGGL((hll_lds_local<double, true, 2048>), dim3(lgrid), dim3(kBlock), llds, s,
                                        m->local_blocks, lchunk, m->ldesc4, m->ldesc, m->lines, m->row_seg,
                                        m->lja, m->AS, x, y);

@@ -290,6 +290,12 @@ struct spmv_hll_dev {
     int *lines = nullptr;
     unsigned short *lja = nullptr;
     unsigned *row_seg = nullptr;   // [M] a row's (first slot in its window | slots << 16)
+    // the pattern plan of the windows (round 3; see spmv_csr_dev): hll_lds_local<.., PAT> does not read lja
+    unsigned short *ptab = nullptr;
+    unsigned *rinfo = nullptr;
+    int2 *pdesc = nullptr;
+    long long pat_slots = 0;
+    float pat_with_us = 0, pat_without_us = 0;
     spmv_csr_dev *tiles = nullptr; // csr_tile over the slab's rows (padding slots included), when the slab gets no x-window plan
     int local_blocks = 0, local_stage_lines = 0;
     long long local_lines = 0;

@@ -1297,6 +1297,69 @@ def test_pattern_plan_rebuilds_the_slots_bit_for_bit(gpu, oracle, dtype):
     run(n, n, rp3, col3[order], val3, True, True)
 
 
+def test_hll_pattern_plan_rebuilds_the_slots_bit_for_bit(gpu, oracle):
+    """The HLL twin (hll_lds_local<.., PAT>): in a slab every row of a hack has the hack's length, padding included, so
+    the windows of a stencil's slab are rows shifted by a constant as well.  Forced plan against the same handle through
+    the 16-bit slot stream: the same bits; both builders of the slab (host, from a resident CSR handle); hacks of
+    different lengths, empty rows, a hack range of a bigger matrix."""
+    from sparsematrixvectormultiplication_amd import synth
+    from sparsematrixvectormultiplication_amd.device import set_tuning
+    rng = np.random.default_rng(93)
+    M, rp, col, val = synth.kkt_like((24, 24, 25), 5)
+    x = rng.uniform(-1, 1, M)
+    ref = oracle.csr_serial(rp, col, val, x)
+
+    def check(dev, lo=0, hi=M):
+        info = dev.info()
+        assert info["local_blocks"] > 0 and 0 < info["pattern_slots"] * 2 <= info["slots"]
+        sp.lib().spmv_hip_memset(dev.y_ptr, 0xFF, M * 8)
+        y = dev.spmv(x, sp.HLL_LDS)[lo:hi].copy()
+        assert np.max(np.abs(y - ref[lo:hi])) <= 1e-10 * np.max(np.abs(ref))
+        set_tuning("local_patterns", 0)                           # the same handle through the slot stream
+        y0 = dev.spmv(x, sp.HLL_LDS)[lo:hi].copy()
+        set_tuning("local_patterns", 1)
+        assert y.tobytes() == y0.tobytes()
+
+    set_tuning("local_patterns", 1)
+    try:
+        hll = sp.convert_to_hll(sp.PreMatrix.from_arrays(M, M, np.repeat(np.arange(M, dtype=np.int32), np.diff(rp)), col, val))
+        with sp.HllDevice(hll) as dev:
+            check(dev)
+        hacks = (M + 31) // 32
+        h0, h1 = hacks // 3, 2 * hacks // 3
+        with sp.HllDevice(hll, h0, h1) as part:
+            check(part, 32 * h0, min(M, 32 * h1))
+        with sp.CsrDevice(M, M, rp, col, val) as cdev:
+            with sp.HllDevice.from_csr_device(cdev) as dev2:
+                check(dev2)
+        # rows of different lengths inside a hack (padding becomes part of the patterns), every 9th row empty
+        n = 30000
+        lens = np.where(np.arange(n) % 9 == 4, 0, 3 + (np.arange(n) % 5))
+        rp2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(n), lens)
+        within = np.concatenate([np.arange(k) for k in lens]) if lens.sum() else np.zeros(0, int)
+        col2 = np.clip(rows + 2 * within - 3, 0, n - 1).astype(np.int32)
+        order = np.lexsort((col2, rows))
+        col2 = col2[order]
+        keep = np.ones(len(col2), bool)
+        keep[1:] = (rows[order][1:] != rows[order][:-1]) | (col2[1:] != col2[:-1])
+        rows2, col2 = rows[order][keep], col2[keep]
+        rp2 = np.zeros(n + 1, np.int64)
+        np.add.at(rp2, rows2 + 1, 1)
+        rp2 = np.cumsum(rp2).astype(np.int32)
+        val2 = rng.uniform(-1, 1, len(col2))
+        x2 = rng.uniform(-1, 1, n)
+        ref2 = oracle.csr_serial(rp2, col2, val2, x2)
+        with sp.HllDevice(sp.convert_to_hll(sp.PreMatrix.from_arrays(n, n, rows2.astype(np.int32), col2, val2))) as dev3:
+            assert dev3.info()["pattern_slots"] > 0
+            y = dev3.spmv(x2, sp.HLL_LDS)
+            assert np.max(np.abs(y - ref2)) <= 1e-10 * np.max(np.abs(ref2))
+            set_tuning("local_patterns", 0)
+            assert dev3.spmv(x2, sp.HLL_LDS).tobytes() == y.tobytes()
+    finally:
+        set_tuning("local_patterns", -1)
+
+
 def test_pattern_plan_fuzz(gpu, oracle):
     """tests/fuzz_patterns.py with a few dozen cases: random shapes through the forced pattern plan, bit for bit against
     the slot stream and against the oracle within the gate."""
