@@ -53,6 +53,7 @@ def make_case(rng, case):
 def run(cases=60, seed=2027, oracle=None):
     rng = np.random.default_rng(seed)
     with_plan = 0
+    hll_with_plan = [0]
     for case in range(cases):
         dtype = np.float32 if case % 4 == 3 else np.float64
         M, N, rp, col = make_case(rng, case)
@@ -75,8 +76,19 @@ def run(cases=60, seed=2027, oracle=None):
                     ref = (oracle.csr_serial if dtype == np.float64 else oracle.csr_f32_accum64)(rp, col, val, x)[r0:r1]
                     tol = 1e-10 if dtype == np.float64 else 1e-5
                     assert np.max(np.abs(y1.astype(np.float64) - ref)) <= tol * max(np.max(np.abs(ref)), 1e-300), f"case {case}"
+                # the HLL twin on the slab built from this handle (fp64, whole matrices)
+                if dtype == np.float64 and (r0, r1) == (0, M) and case % 2 == 0:
+                    set_tuning("local_patterns", 1)
+                    with sp.HllDevice.from_csr_device(dev) as hdev:
+                        if hdev.info()["local_blocks"] and hdev.info()["pattern_slots"]:
+                            h1 = hdev.spmv(x, sp.HLL_LDS).copy()
+                            set_tuning("local_patterns", 0)
+                            h0 = hdev.spmv(x, sp.HLL_LDS).copy()
+                            assert h1.tobytes() == h0.tobytes(), f"HLL case {case}: M={M} N={N} nnz={len(col)}"
+                            hll_with_plan[0] += 1
         finally:
             set_tuning("local_patterns", -1)
+    run.hll_with_plan = hll_with_plan[0]
     return with_plan
 
 
@@ -84,4 +96,4 @@ if __name__ == "__main__":
     sp.hip_init(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2027
-    print(f"{run(n, seed)} of {n} cases had a pattern plan; all equal to the slot stream bit for bit")
+    print(f"{run(n, seed)} of {n} cases had a pattern plan ({run.hll_with_plan} HLL slabs of them as well); all equal to the slot stream bit for bit")
