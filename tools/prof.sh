@@ -11,7 +11,9 @@ export TMPDIR=/tmp
 # (upload's placement search launches the kernel a few dozen times more: off here, so that the per-product division of
 # the counters in tools/prof_traffic.py stays exact; the JSON line of every pass -- trace.log, pmc_*.log -- carries the
 # box record and the placement the pass ran on)
-export SPMV_TUNING="${SPMV_TUNING:+$SPMV_TUNING,}place_tries=0"
+# (the same for upload's with / without timing of the pattern plan: here the plan is simply kept -- what the un-profiled
+# bench decides for this workload on every box seen, config.pattern_plan in its line)
+export SPMV_TUNING="${SPMV_TUNING:+$SPMV_TUNING,}place_tries=0,local_patterns=1"
 BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 # counters in their own passes (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2)
