@@ -5,6 +5,8 @@
 #include "spmv_internal.hpp"
 
 #include "plan_kernels.hpp"
+#include <chrono>
+
 #include "tile_plan.hpp"
 #include "tile_plan_device.hpp"
 
@@ -1184,6 +1186,17 @@ int csr_upload_impl(int M, int N, const int *row_ptr, const int *col_idx, const 
     if (!have_local && !tb.have_tiles && nz < (20LL << 20) && max_row <= std::max(64.0, 8.0 * mean))
         m->auto_variant = SPMV_CSR_SUBWAVE;
     trace.mark("blocks, remaining uploads, vectors");
+    // Both searches below compare launch times: they begin in the card's steady state -- after an idle stretch (this
+    // upload) the same launch costs 178, then 208, then, from about the 60th on, 175 us (profiles/r3_launch_time_series.txt),
+    // a drift as large as what the searches look for.  ~15 ms of the handle's own kernel first.
+    if ((m->ptab && g_local_patterns < 0) || (g_place_tries > 0 && (size_t)m->nz * sizeof(T) >= ((size_t)128 << 20) && m->val && !m->tiles_only)) {
+        const auto t_settle = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_settle).count() < 15.0) {
+            bool bad = false;
+            for (int i = 0; i < 16 && !bad; ++i) bad = csr_launch_any(m, SPMV_CSR_AUTO, m->x, m->y, g_stream) != 0;
+            if (bad || hipStreamSynchronize(g_stream) != hipSuccess) break;
+        }
+    }
     (void)csr_tune_patterns(m);      // (auto) the pattern plan stays only where it measures faster on this handle
     (void)csr_tune_placement<T>(m);  // (never a reason to lose the handle: whatever went wrong in there, it holds a valid array)
     trace.mark("placement tuning");
