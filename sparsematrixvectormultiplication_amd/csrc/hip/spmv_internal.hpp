@@ -431,14 +431,24 @@ template <typename Launch>
 int step_loop(void *y, int value_bytes, const int *bounds, int warmup, int iters, float *ms_kernel,
               float *ms_exchange, Launch launch) {
     if (iters <= 0) return fail("step_time: iters must be > 0");
-    std::vector<hipEvent_t> ev((size_t)iters * 3, nullptr);
+    // (events kept from call to call, per device: see time_loop)
+    static std::vector<hipEvent_t> pool;
+    static int pool_device = -1;
     int rc = 0;
     auto hip_ok = [&](hipError_t e, const char *what) {
         if (e != hipSuccess && !rc) rc = fail("step_time: %s failed: %s", what, hipGetErrorString(e));
         return e == hipSuccess;
     };
-    for (auto &e : ev)
-        if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) break;
+    if (pool_device != g_device) {
+        pool.clear();
+        pool_device = g_device;
+    }
+    while (pool.size() < (size_t)iters * 3) {
+        hipEvent_t e = nullptr;
+        if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) return rc;
+        pool.push_back(e);
+    }
+    hipEvent_t *ev = pool.data();
     for (int i = -warmup; i < iters && !rc; ++i) {
         if (i >= 0 && !hip_ok(hipEventRecord(ev[3 * i], g_stream), "hipEventRecord")) break;
         rc = launch();
@@ -457,7 +467,5 @@ int step_loop(void *y, int value_bytes, const int *bounds, int warmup, int iters
             if (ms_exchange) ms_exchange[i] = b;
         }
     }
-    for (auto &e : ev)
-        if (e) (void)hipEventDestroy(e);
     return rc;
 }
