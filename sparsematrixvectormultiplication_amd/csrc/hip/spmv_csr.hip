@@ -922,6 +922,7 @@ int csr_tune_patterns(spmv_csr_dev *m) {
         m->ptab = nullptr;
         m->rinfo = nullptr;
         m->pdesc = nullptr;
+        m->device_bytes -= std::min(m->device_bytes, ((size_t)m->pat_slots + 1024) * 2 + (size_t)m->M_local * 4 + (size_t)m->local_blocks * 8);
         m->pat_slots = 0;
     }
     return 0;

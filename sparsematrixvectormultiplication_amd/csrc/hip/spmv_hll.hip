@@ -391,6 +391,7 @@ static void hll_tune_patterns(spmv_hll_dev *m) {
         m->ptab = nullptr;
         m->rinfo = nullptr;
         m->pdesc = nullptr;
+        m->device_bytes -= std::min(m->device_bytes, ((size_t)m->pat_slots + 1024) * 2 + (size_t)m->M * 4 + (size_t)m->local_blocks * 8);
         m->pat_slots = 0;
     }
 }
